@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ -- run in the BUILD CONTAINER only.
+
+    python tests/golden/make_golden.py            # needs /root/reference (read-only)
+
+What is executed
+----------------
+The reference's OWN code, loaded from /root/reference at run time (nothing from the
+reference is copied into this repository):
+
+* ``algs.MoreauYosidaUnadjustedLangevin`` / ``algs.UnadjustedLangevinPrimalDual`` /
+  ``algs.L2_ncvx_tv`` (algs.py) -- the sampler loops and the non-log-concave data term;
+* ``lmc.LangevinMonteCarlo.ula``, ``prox_lmc.ProximalLangevinMonteCarlo.{myula,pgld}``;
+* the closed-form proxes of ``prox.py``.
+
+The reference imports modules that are not installed in this image and cannot be fetched
+(no network): pylops, pyproximal, fire, fastprogress, seaborn, scienceplots, ot.  They are
+replaced by inert namespace stand-ins (no arithmetic; ``progress_bar`` is the identity
+iterator).  The operator objects that pylops / pyproximal would supply (blur, gradient,
+L2 / L1 / L21 / TV proxes) are the oracle's restatements (``oracle/lmc_oracle.py``), passed
+into the reference loops through the duck-typed protocol the loops consume.  Hence the
+vectors pin: recursion, step formulae, RNG consumption order, output layout, closed-form
+proxes, L2_ncvx_tv's own formulae.  They do NOT pin pylops/pyproximal arithmetic
+("parity unpinned", see oracle header).
+
+A second, independent fixture (``tv_chambolle.npz``) is produced with
+``/opt/conda/bin/python3.9`` + scikit-image 0.18.3 (``denoise_tv_chambolle``), a converged
+ROF solver that shares nothing with this repository, to check the oracle's TV prox at
+convergence.
+"""
+import importlib.util
+import os
+import subprocess
+import sys
+import types
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+import numpy as np
+import scipy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+from oracle import lmc_oracle as O  # noqa: E402
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_standins():
+    class ProxOperator:                      # namespace-only base, as algs.py:132 expects
+        def __init__(self, Op=None, hasgrad=False):
+            self.Op, self.hasgrad = Op, hasgrad
+
+    _mod("pylops", MatrixMult=None, Identity=None)
+    _mod("pylops.optimization")
+    _mod("pylops.optimization.basic", lsqr=None)
+    _mod("pylops.utils")
+    _mod("pylops.utils.backend", get_array_module=lambda x: np,
+         get_module_name=lambda m: "numpy", to_numpy=lambda x: x)
+    # L2_ncvx_tv.__init__ instantiates pyproximal.L1 / pyproximal.TV (algs.py:166,169):
+    # hand it the oracle's restatements of those two operators.
+    _mod("pyproximal", ProxOperator=ProxOperator, L1=O.L1,
+         TV=lambda dims, sigma, niter, rtol: O.TV(dims, sigma, niter, rtol=0.0))
+    _mod("pyproximal.ProxOperator", _check_tau=lambda f: f)
+    _mod("fastprogress", progress_bar=lambda it, *a, **k: it)
+    _mod("fire", Fire=lambda *a, **k: None)
+    _mod("seaborn")
+    _mod("scienceplots")
+    ot = _mod("ot")
+    ot.plot = _mod("ot.plot")
+    import matplotlib.style.core as msc
+    for s in ("science", "grid"):
+        msc.library.setdefault(s, {})
+
+
+def load_ref(name):
+    spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(REF, name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    if name == "prox_lmc":
+        sys.modules["prox"] = load_ref("prox")
+    spec.loader.exec_module(m)
+    return m
+
+
+def versions():
+    return np.array(f"numpy {np.__version__}; scipy {scipy.__version__}; python {sys.version.split()[0]}")
+
+
+def synth_image(ny, nx, seed):
+    """Piecewise-constant blocks + ramp in [0,255] (no file I/O)."""
+    rng = np.random.default_rng(seed)
+    img = np.zeros((ny, nx))
+    for _ in range(6):
+        i0, j0 = rng.integers(0, ny - 2), rng.integers(0, nx - 2)
+        i1, j1 = rng.integers(i0 + 1, ny + 1), rng.integers(j0 + 1, nx + 1)
+        img[i0:i1, j0:j1] = rng.uniform(20, 235)
+    img += np.linspace(0, 20, nx)[None, :]
+    return np.clip(img, 0, 255)
+
+
+def deconv_problem(ny, nx, k, sigma, seed):
+    """Mirror of prox_lmc_deconv.py:52-59,88-94 on a synthetic image."""
+    img = synth_image(ny, nx, 1234)
+    rng = np.random.default_rng(seed)
+    h = np.ones((k, k)) / (k * k)
+    Hop = O.Convolve2D((ny, nx), h, offset=(k // 2, k // 2))
+    y = (Hop * img.ravel()).reshape(ny, nx) + rng.normal(0, sigma, size=(ny, nx))
+    return img, h, Hop, y
+
+
+def gen_toy(out):
+    lmc = load_ref("lmc")
+    plmc = load_ref("prox_lmc")
+    d = {}
+    # BASELINE config 1: 1-D N(0,1), 1 chain, 1000 iterations, gamma = 5e-2, seed 0
+    mus, Sig, om = [np.array([0.0])], [np.array([[1.0]])], [1.0]
+    d["c1_ula"] = lmc.LangevinMonteCarlo(mus, Sig, om, K=1000, seed=0).ula(5e-2)
+    p = plmc.ProximalLangevinMonteCarlo(mus, Sig, om, lamda=0.25, alpha=0.15, mu=0.0, K=1000, seed=0)
+    d["c1_myula"] = p.myula(5e-2)
+    d["c1_pgld"] = p.pgld(5e-2)
+    # 2-D, 2-component mixture
+    mus2 = [np.array([0.0, 0.0]), np.array([3.0, -1.0])]
+    Sig2 = [np.array([[1.0, 0.3], [0.3, 0.8]]), np.array([[0.5, -0.1], [-0.1, 1.2]])]
+    om2 = [0.4, 0.6]
+    d["m2_ula"] = lmc.LangevinMonteCarlo(mus2, Sig2, om2, K=300, seed=3).ula(1e-1)
+    p2 = plmc.ProximalLangevinMonteCarlo(mus2, Sig2, om2, lamda=0.25, alpha=0.15, mu=0.0, K=300, seed=3)
+    d["m2_myula"] = p2.myula(5e-2)
+    d["m2_pgld"] = p2.pgld(5e-2)
+    d["m2_mus"], d["m2_Sigmas"], d["m2_omegas"] = np.array(mus2), np.array(Sig2), np.array(om2)
+    d["versions"] = versions()
+    np.savez_compressed(out, **d)
+
+
+def gen_prox(out):
+    P = load_ref("prox")
+    x = np.concatenate([np.linspace(-6, 6, 49), np.array([0.0, 1e-9, -1e-9, 0.3, -0.3, 2.5])])
+    xp = np.abs(x) + 0.05
+    d = {"x": x, "xp": xp}
+    d["laplace_0.5"] = P.prox_laplace(x, 0.5)
+    d["uncentered_laplace_0.7_1.5"] = P.prox_uncentered_laplace(x, 0.7, 1.5)
+    d["gaussian_0.3"] = P.prox_gaussian(x, 0.3)
+    d["conjugate_laplace_0.8"] = P.prox_conjugate(x, 0.8, P.prox_laplace)
+    for name, p in (("4_3", 4 / 3), ("3_2", 3 / 2), ("3", 3), ("4", 4)):
+        d["gen_gaussian_0.6_" + name] = P.prox_gen_gaussian(x, 0.6, p)
+    d["huber_0.5_0.4"] = np.array([P.prox_huber(v, 0.5, 0.4) for v in x])      # scalar-only in the reference
+    d["smoothed_laplace_0.9"] = P.prox_smoothed_laplace(x, 0.9)
+    d["exp_0.5"] = np.array([P.prox_exp(v, 0.5) for v in x])
+    d["gamma_0.4_1.3"] = P.prox_gamma(x, 0.4, 1.3)
+    d["chi_0.7"] = P.prox_chi(x, 0.7)
+    d["uniform_1.2"] = np.array([P.prox_uniform(v, 1.2) for v in x])
+    d["triangular_-0.5_0.8"] = np.array([P.prox_triangular(v, -0.5, 0.8) for v in x])
+    d["versions"] = versions()
+    np.savez_compressed(out, **d)
+
+
+def gen_algs(out):
+    A = load_ref("algs")
+    d = {}
+    sigma = 0.75
+    tau_reg = 0.3
+    L = 1.0 / sigma ** 2
+    gamma_myula = 1.0 / L
+    tau_myula = 0.2 * gamma_myula                     # prox_lmc_deconv.py:92-94
+    tau0, mu0 = 0.95 / L, 1.0                         # prox_lmc_deconv.py:88-90
+    cases = [("a", 16, 16, 5, 0), ("b", 20, 24, 6, 1), ("c", 24, 18, 7, 2)]
+    for tag, ny, nx, k, seed in cases:
+        img, h, Hop, y = deconv_problem(ny, nx, k, sigma, seed)
+        d[f"{tag}_img"], d[f"{tag}_h"], d[f"{tag}_y"] = img, h, y
+        d[f"{tag}_meta"] = np.array([ny, nx, k, seed])
+        x0 = np.zeros(ny * nx)
+        Gop = O.Gradient((ny, nx))
+        # --- MYULA with TV / L1 / L2 priors (prox_lmc_deconv.py:465)
+        priors = {"tv": O.TV((ny, nx), sigma=tau_reg, niter=10),
+                  "l1": O.L1(sigma=tau_reg),
+                  "l2": O.L2(sigma=0.05)}
+        for pname, pg in priors.items():
+            if tag != "a" and pname != "tv":
+                continue                              # keep the fixture small
+            l2 = O.L2(Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, niter=50, warm=True)
+            cb = []
+            s = A.MoreauYosidaUnadjustedLangevin(l2, pg, tau=tau_myula, gamma=gamma_myula, x0=x0,
+                                                 niter=16, seed=seed, callback=lambda x: cb.append(x[0]))
+            assert s.shape == (16, ny * nx) and len(cb) == 16
+            d[f"{tag}_myula_{pname}"] = s
+        # --- ULPDA (prox_lmc_deconv.py:455-457), both orders, with dual output
+        for gfirst in (False, True):
+            l2 = O.L2(Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, niter=50, warm=True)
+            xs, ys = A.UnadjustedLangevinPrimalDual(l2, O.L21(ndim=2, sigma=tau_reg), Gop, tau=tau0, mu=mu0,
+                                                    theta=1.0, x0=x0, gfirst=gfirst, niter=8, seed=seed,
+                                                    returny=True)
+            d[f"{tag}_ulpda_l21_gfirst{int(gfirst)}_x"] = xs
+            d[f"{tag}_ulpda_l21_gfirst{int(gfirst)}_y"] = ys
+        if tag == "a":
+            l2 = O.L2(Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, niter=50, warm=True)
+            d[f"{tag}_ulpda_l1"] = A.UnadjustedLangevinPrimalDual(l2, O.L1(sigma=tau_reg), Gop, tau=tau0, mu=mu0,
+                                                                  theta=1.0, x0=x0, gfirst=False, niter=8, seed=seed)
+        # --- L2_ncvx_tv (prox_lmc_deconv.py:106-113): value and gradient, MC-TV and ME-TV
+        rng = np.random.default_rng(100 + seed)
+        xt = (img + rng.normal(0, 5.0, img.shape)).ravel()
+        mc = A.L2_ncvx_tv(dims=(ny, nx), Op=Hop, Op2=Gop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg,
+                          gamma=15.0, isotropic=True, niter=50, warm=True)
+        me = A.L2_ncvx_tv(dims=(ny, nx), Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg,
+                          gamma=15.0, isotropic=True, niter=50, warm=True)
+        d[f"{tag}_ncvx_x"] = xt
+        d[f"{tag}_ncvx_mc_grad"], d[f"{tag}_ncvx_mc_val"] = mc.grad(xt.copy()), np.array(mc(xt.copy()))
+        d[f"{tag}_ncvx_me_grad"], d[f"{tag}_ncvx_me_val"] = me.grad(xt.copy()), np.array(me(xt.copy()))
+        # MYULA with the non-log-concave data term (prox_lmc_deconv.py:492-501 pattern)
+        d[f"{tag}_myula_mc_tv"] = A.MoreauYosidaUnadjustedLangevin(
+            mc, O.TV((ny, nx), sigma=tau_reg, niter=10), tau=tau_myula, gamma=gamma_myula, x0=x0, niter=6, seed=seed)
+    d["params"] = np.array([sigma, tau_reg, tau_myula, gamma_myula, tau0, mu0])
+    d["versions"] = versions()
+    np.savez_compressed(out, **d)
+
+
+CHAMBOLLE = r'''
+import sys, numpy as np
+from skimage.restoration import denoise_tv_chambolle
+import skimage
+x = np.load(sys.argv[1])["x"]
+res = {}
+for w in (0.16875, 2.0, 15.0):
+    res["w_%g" % w] = denoise_tv_chambolle(x, weight=w, eps=1e-12, n_iter_max=20000)
+res["versions"] = np.array("skimage %s numpy %s" % (skimage.__version__, np.__version__))
+np.savez_compressed(sys.argv[2], x=x, **res)
+'''
+
+
+def gen_chambolle(out):
+    py39 = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py39):
+        print("skip tv_chambolle.npz: no", py39)
+        return
+    img = synth_image(24, 20, 1234) + np.random.default_rng(5).normal(0, 8.0, (24, 20))
+    tmp = "/tmp/_chamb_in.npz"
+    np.savez(tmp, x=img)
+    subprocess.run([py39, "-W", "ignore", "-c", CHAMBOLLE, tmp, out], check=True)
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("needs the reference at /root/reference (build container only)")
+    install_standins()
+    gen_toy(os.path.join(HERE, "toy.npz"))
+    gen_prox(os.path.join(HERE, "prox.npz"))
+    gen_algs(os.path.join(HERE, "algs.npz"))
+    gen_chambolle(os.path.join(HERE, "tv_chambolle.npz"))
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -1,0 +1,139 @@
+"""Oracle (oracle/lmc_oracle.py) against the golden vectors produced by the reference's
+own code (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import lmc_oracle as O
+
+
+# ---------------------------------------------------------------- BASELINE config 1 (toy)
+def test_config1_ula_matches_reference(golden):
+    g = golden("toy.npz")
+    mus, Sig, om = [np.array([0.0])], [np.array([[1.0]])], [1.0]
+    out = O.toy_ula(mus, Sig, om, 5e-2, K=1000, seed=0)
+    assert out.shape == g["c1_ula"].shape == (1000, 1)
+    np.testing.assert_allclose(out, g["c1_ula"], rtol=0, atol=1e-12)
+    # values captured in SURVEY.md section 8c
+    np.testing.assert_allclose(g["c1_ula"][:3, 0], [0.07766848, 0.27630448, 0.29566159], atol=1e-8)
+
+
+def test_config1_myula_pgld_match_reference(golden):
+    g = golden("toy.npz")
+    mus, Sig, om = [np.array([0.0])], [np.array([[1.0]])], [1.0]
+    np.testing.assert_allclose(O.toy_myula(mus, Sig, om, 0.25, 0.15, 5e-2, K=1000, seed=0), g["c1_myula"], atol=1e-12)
+    np.testing.assert_allclose(O.toy_pgld(mus, Sig, om, 0.25, 0.15, 5e-2, K=1000, seed=0), g["c1_pgld"], atol=1e-12)
+    np.testing.assert_allclose(g["c1_myula"][:2, 0], [0.07016848, 0.26167948], atol=1e-8)
+    np.testing.assert_allclose(g["c1_pgld"][:2, 0], [0.04204348, 0.20683573], atol=1e-8)
+
+
+def test_mixture2d_matches_reference(golden):
+    g = golden("toy.npz")
+    mus, Sig, om = list(g["m2_mus"]), list(g["m2_Sigmas"]), list(g["m2_omegas"])
+    np.testing.assert_allclose(O.toy_ula(mus, Sig, om, 1e-1, K=300, seed=3), g["m2_ula"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(O.toy_myula(mus, Sig, om, 0.25, 0.15, 5e-2, K=300, seed=3), g["m2_myula"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(O.toy_pgld(mus, Sig, om, 0.25, 0.15, 5e-2, K=300, seed=3), g["m2_pgld"], rtol=1e-11, atol=1e-11)
+
+
+# ---------------------------------------------------------------- prox.py library
+def test_prox_library_matches_reference(golden):
+    g = golden("prox.npz")
+    x = g["x"]
+    tol = dict(rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(O.prox_laplace(x, 0.5), g["laplace_0.5"], **tol)
+    np.testing.assert_allclose(O.prox_uncentered_laplace(x, 0.7, 1.5), g["uncentered_laplace_0.7_1.5"], **tol)
+    np.testing.assert_allclose(O.prox_gaussian(x, 0.3), g["gaussian_0.3"], **tol)
+    np.testing.assert_allclose(O.prox_conjugate(x, 0.8, O.prox_laplace), g["conjugate_laplace_0.8"], **tol)
+    for name, p in (("4_3", 4 / 3), ("3_2", 3 / 2), ("3", 3), ("4", 4)):
+        np.testing.assert_allclose(O.prox_gen_gaussian(x, 0.6, p), g["gen_gaussian_0.6_" + name], **tol)
+    np.testing.assert_allclose(O.prox_huber(x, 0.5, 0.4), g["huber_0.5_0.4"], **tol)
+    np.testing.assert_allclose(O.prox_smoothed_laplace(x, 0.9), g["smoothed_laplace_0.9"], **tol)
+    np.testing.assert_allclose(O.prox_exp(x, 0.5), g["exp_0.5"], **tol)
+    np.testing.assert_allclose(O.prox_gamma(x, 0.4, 1.3), g["gamma_0.4_1.3"], **tol)
+    np.testing.assert_allclose(O.prox_chi(x, 0.7), g["chi_0.7"], **tol)
+    np.testing.assert_allclose(O.prox_uniform(x, 1.2), g["uniform_1.2"], **tol)
+    np.testing.assert_allclose(O.prox_triangular(x, -0.5, 0.8), g["triangular_-0.5_0.8"], **tol)
+    # SURVEY A.1 probe
+    np.testing.assert_allclose(O.prox_laplace(np.array([-2, -.1, 0, .3, 5]), .5), [-1.5, -0., 0., 0., 4.5])
+
+
+# ---------------------------------------------------------------- algs.py loops
+CASES = ["a", "b", "c"]
+
+
+def _problem(g, tag):
+    ny, nx, k, seed = [int(v) for v in g[f"{tag}_meta"]]
+    h, y = g[f"{tag}_h"], g[f"{tag}_y"]
+    Hop = O.Convolve2D((ny, nx), h, offset=(k // 2, k // 2))
+    return ny, nx, k, seed, Hop, y
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_myula_matches_reference_loop(golden, tag):
+    g = golden("algs.npz")
+    sigma, tau_reg, tau_myula, gamma_myula, tau0, mu0 = g["params"]
+    ny, nx, k, seed, Hop, y = _problem(g, tag)
+    x0 = np.zeros(ny * nx)
+    priors = {"tv": O.TV((ny, nx), sigma=tau_reg, niter=10), "l1": O.L1(sigma=tau_reg), "l2": O.L2(sigma=0.05)}
+    for pname, pg in priors.items():
+        key = f"{tag}_myula_{pname}"
+        if key not in g.files:
+            continue
+        l2 = O.L2(Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2)
+        out = O.myula(l2, pg, x0, tau_myula, gamma_myula, niter=g[key].shape[0], seed=seed)
+        assert out.shape == g[key].shape and out.dtype == np.float64
+        np.testing.assert_array_equal(out, g[key])          # same operations in the same order: bit exact
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_ulpda_matches_reference_loop(golden, tag):
+    g = golden("algs.npz")
+    sigma, tau_reg, tau_myula, gamma_myula, tau0, mu0 = g["params"]
+    ny, nx, k, seed, Hop, y = _problem(g, tag)
+    x0 = np.zeros(ny * nx)
+    Gop = O.Gradient((ny, nx))
+    for gfirst in (False, True):
+        l2 = O.L2(Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, niter=50, warm=True)
+        gx, gy = g[f"{tag}_ulpda_l21_gfirst{int(gfirst)}_x"], g[f"{tag}_ulpda_l21_gfirst{int(gfirst)}_y"]
+        xs, ys = O.ulpda(l2, O.L21(ndim=2, sigma=tau_reg), Gop, x0, tau0, mu0, theta=1.0, niter=gx.shape[0],
+                         seed=seed, gfirst=gfirst, returny=True)
+        np.testing.assert_array_equal(xs, gx)
+        np.testing.assert_array_equal(ys, gy)
+    if f"{tag}_ulpda_l1" in g.files:
+        l2 = O.L2(Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, niter=50, warm=True)
+        gx = g[f"{tag}_ulpda_l1"]
+        xs = O.ulpda(l2, O.L1(sigma=tau_reg), Gop, x0, tau0, mu0, theta=1.0, niter=gx.shape[0], seed=seed, gfirst=False)
+        np.testing.assert_array_equal(xs, gx)
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_l2_ncvx_tv_matches_reference_class(golden, tag):
+    g = golden("algs.npz")
+    sigma, tau_reg, tau_myula, gamma_myula, tau0, mu0 = g["params"]
+    ny, nx, k, seed, Hop, y = _problem(g, tag)
+    Gop = O.Gradient((ny, nx))
+    xt = g[f"{tag}_ncvx_x"]
+    mc = O.L2NcvxTV((ny, nx), Op=Hop, Op2=Gop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=15.0, niter=50)
+    me = O.L2NcvxTV((ny, nx), Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=15.0, niter=50)
+    np.testing.assert_allclose(mc.grad(xt.copy()), g[f"{tag}_ncvx_mc_grad"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(me.grad(xt.copy()), g[f"{tag}_ncvx_me_grad"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(mc(xt.copy()), g[f"{tag}_ncvx_mc_val"], rtol=1e-12)
+    np.testing.assert_allclose(me(xt.copy()), g[f"{tag}_ncvx_me_val"], rtol=1e-12)
+    gx = g[f"{tag}_myula_mc_tv"]
+    out = O.myula(mc, O.TV((ny, nx), sigma=tau_reg, niter=10), np.zeros(ny * nx), tau_myula, gamma_myula,
+                  niter=gx.shape[0], seed=seed)
+    np.testing.assert_allclose(out, gx, rtol=1e-12, atol=1e-11)
+
+
+def test_batched_step_equals_single_chain_loop(golden):
+    """myula_step (image-shaped, batched -- the form the device parity tests use) is the same
+    recursion as the reference loop."""
+    g = golden("algs.npz")
+    sigma, tau_reg, tau_myula, gamma_myula, tau0, mu0 = g["params"]
+    ny, nx, k, seed, Hop, y = _problem(g, "b")
+    ref = g["b_myula_tv"]
+    rng = np.random.default_rng(seed)
+    noise = rng.standard_normal((ref.shape[0], ny, nx))
+    prior = {"kind": "tv", "sigma": tau_reg, "niter": 10, "t": gamma_myula}
+    x = O.myula_batched(np.zeros((1, ny, nx)), y, g["b_h"], (k // 2, k // 2), 1 / sigma ** 2, tau_myula, gamma_myula,
+                        prior, ref.shape[0], lambda it: noise[it][None])
+    np.testing.assert_allclose(x[0].ravel(), ref[-1], rtol=1e-12, atol=1e-11)
