@@ -1,0 +1,190 @@
+/* lmc_atomi.h -- C ABI of the MI355X-native LMC hot path (liblmc_atomi.so).
+ *
+ * The reference (192459/lmc-atomi) is pure Python and has no FFI: its hot path sits behind
+ * duck-typed Python protocols.  This header is the boundary a maintainer of the reference
+ * would bind (ctypes stub in INTEGRATION.md); each entry point names the reference
+ * interface it replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *  - plain C, no HIP/torch types: `stream` is a hipStream_t passed as void* (NULL = default
+ *    stream); pointers ending in _dev are device (HBM) pointers, _host are host pointers.
+ *  - every function returns 0 (LMC_OK) or a negative lmc_status; lmc_last_error() gives the
+ *    thread-local message of the last failure.  No exception crosses the boundary.
+ *  - images are fp32, row-major [H][W] (W fastest); chain states are [C][H][W];
+ *    the stacked gradient field is [2][H][W] per image (row-differences first), as the
+ *    reference's 2n vectors (algs.py:427).
+ *  - the caller owns every buffer it passes; a sampler owns its state/scratch buffers.
+ *  - calls on one sampler handle must be serialised by the caller; all work is enqueued on
+ *    the given stream; functions that return host values synchronise that stream.
+ */
+#ifndef LMC_ATOMI_H
+#define LMC_ATOMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMC_ATOMI_ABI_VERSION 1
+
+typedef enum lmc_status {
+  LMC_OK = 0,
+  LMC_E_INVALID = -1,     /* bad argument / inconsistent configuration */
+  LMC_E_UNSUPPORTED = -2, /* valid request this build has no kernel for */
+  LMC_E_HIP = -3,         /* a HIP runtime call failed */
+  LMC_E_NOMEM = -4,
+  LMC_E_STATE = -5        /* call not allowed in the handle's current state */
+} lmc_status;
+
+/* data-fidelity term f(x) = sigma_f/2 * || Op x - y ||^2  (pyproximal.L2 as built at
+ * prox_lmc_deconv.py:101-103; same formulae in-repo at algs.py:182-187, 283-288) */
+typedef enum lmc_data_kind {
+  LMC_DATA_NONE = 0,     /* f = 0 */
+  LMC_DATA_IDENTITY = 1, /* Op = I */
+  LMC_DATA_BLUR = 2,     /* Op = zero-padded "same" convolution, pylops Convolve2D (prox_lmc_deconv.py:55-69) */
+  LMC_DATA_MASK = 3      /* Op = diag(mask), inpainting (BASELINE config 5) */
+} lmc_data_kind;
+
+/* prior g whose prox enters the MYULA update (algs.py:569) */
+typedef enum lmc_prior_kind {
+  LMC_PRIOR_NONE = 0,   /* prox = identity */
+  LMC_PRIOR_L2 = 1,     /* g = sigma/2 ||x||^2      : prox_t = x / (1 + t*sigma)          */
+  LMC_PRIOR_L1 = 2,     /* g = sigma ||x||_1        : soft threshold t*sigma  (prox.py:18) */
+  LMC_PRIOR_TV_ISO = 3  /* g = sigma TV_iso(x)      : tv_niter FGP dual iterations (pyproximal.TV, prox_lmc_deconv.py:122) */
+} lmc_prior_kind;
+
+typedef enum lmc_noise_mode {
+  LMC_NOISE_PHILOX = 0,   /* counter-based Philox4x32-10 + Box-Muller, keyed by (seed, iteration, global chain, pixel) */
+  LMC_NOISE_INJECTED = 1, /* caller supplies xi (parity tests: replaces algs.py:565) */
+  LMC_NOISE_NONE = 2
+} lmc_noise_mode;
+
+#define LMC_MAX_BLUR 9       /* kernels up to 9x9 */
+#define LMC_MAX_TV_ITERS 64
+
+/* Geometry + potential U(x) = f(x) + eps*g(x).  Plain data; copied by the callee. */
+typedef struct lmc_problem {
+  uint32_t struct_size;     /* = sizeof(lmc_problem) */
+  int32_t H, W;
+  /* data term */
+  int32_t data_kind;        /* lmc_data_kind */
+  float sigma_f;            /* multiplies the L2 term: 1/sigma^2 at prox_lmc_deconv.py:101 */
+  const float* y_dev;       /* [H][W] observation (borrowed; must outlive every use) */
+  const float* mask_dev;    /* [H][W], LMC_DATA_MASK only */
+  int32_t kh, kw, oy, ox;   /* LMC_DATA_BLUR: kernel size and origin (pylops `offset`) */
+  const float* h_host;      /* kh*kw taps, row-major, host memory */
+  /* prior */
+  int32_t prior_kind;       /* lmc_prior_kind */
+  float prior_sigma;        /* multiplicative coefficient of g (tau_reg = 0.3 at prox_lmc_deconv.py:116-122) */
+  int32_t tv_niter;         /* LMC_PRIOR_TV_ISO: number of dual iterations (niter_tv = 10) */
+  float tv_step;            /* dual step is tv_step / (prox parameter); 0 -> 1/8 */
+  const float* tv_betas_host; /* tv_niter momentum coefficients, host; NULL -> UNLocBoX/pyproximal sequence */
+} lmc_problem;
+
+/* ---- library ------------------------------------------------------------------------- */
+int lmc_version(void);                 /* LMC_ATOMI_ABI_VERSION of the loaded library */
+const char* lmc_last_error(void);      /* thread-local; valid until the next failing call on this thread */
+int lmc_device_info(int* device, int* n_cu, size_t* lds_bytes, size_t* hbm_bytes);
+
+/* ---- operator-level entry points (the prox / linear-operator plugin protocol) -------- */
+
+/* out = H x (adjoint == 0) or H^T x (adjoint != 0) for n_img images.
+ * Replaces Convolve2D.matvec / .rmatvec (prox_lmc_deconv.py:58; algs.py:284). */
+int lmc_blur(const float* x_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W,
+             const float* h_host, int32_t kh, int32_t kw, int32_t oy, int32_t ox, int32_t adjoint, void* stream);
+
+/* out[2][H][W] = forward-difference gradient of x (zero in last row/col); pylops.Gradient.matvec
+ * (prox_lmc_deconv.py:98; algs.py:436,448). */
+int lmc_gradient(const float* x_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W, void* stream);
+/* out[H][W] = Gradient.rmatvec(y[2][H][W]) = -div (algs.py:437,443). */
+int lmc_gradient_adjoint(const float* y_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W, void* stream);
+
+/* out = a*x - t*grad f(x) + b*prox_{pt * g}(x)  for n_img images, one fused launch.
+ *   (a,t,b) = (0,-1,0): out = grad f(x)          -> proxf.grad        (algs.py:569; 283-284)
+ *   (a,t,b) = (0, 0,1): out = prox_{pt*g}(x)     -> proxg.prox(x, pt) (algs.py:569)
+ * `pt` is the prox parameter (epsg*gamma in MYULA). */
+int lmc_fused_eval(const lmc_problem* prob, const float* x_dev, float* out_dev, int64_t n_img,
+                   float a, float t, float b, float pt, void* stream);
+
+/* f_out[i] = f(x_i), g_out[i] = g(x_i) (double, device, n_img each; either may be NULL).
+ * Replaces proxf(x), proxg(x) of the energy log (algs.py:461-466, 578-582). */
+int lmc_energies(const lmc_problem* prob, const float* x_dev, int64_t n_img,
+                 double* f_out_dev, double* g_out_dev, void* stream);
+
+/* Per-pixel projection of the stacked field y[2][H][W] onto the l2 ball (isotropic != 0) or the
+ * box (isotropic == 0) of radius `radius`: L21.proxdual / L1.proxdual (algs.py:436,448). */
+int lmc_dual_project(const float* y_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W,
+                     float radius, int32_t isotropic, void* stream);
+
+/* Closed-form elementwise proxes of prox.py (the functional plugin surface), n elements. */
+typedef enum lmc_eprox_kind {
+  LMC_EPROX_LAPLACE = 0,            /* prox.py:18  params: gamma                */
+  LMC_EPROX_UNCENTERED_LAPLACE = 1, /* prox.py:22  params: gamma, mu            */
+  LMC_EPROX_GAUSSIAN = 2,           /* prox.py:26  params: gamma                */
+  LMC_EPROX_GEN_GAUSSIAN_4_3 = 3,   /* prox.py:31  params: gamma                */
+  LMC_EPROX_GEN_GAUSSIAN_3_2 = 4,   /* prox.py:34                               */
+  LMC_EPROX_GEN_GAUSSIAN_3 = 5,     /* prox.py:36                               */
+  LMC_EPROX_GEN_GAUSSIAN_4 = 6,     /* prox.py:38                               */
+  LMC_EPROX_HUBER = 7,              /* prox.py:44  params: gamma, tau           */
+  LMC_EPROX_SMOOTHED_LAPLACE = 8,   /* prox.py:52  params: gamma                */
+  LMC_EPROX_EXP = 9,                /* prox.py:56  params: gamma                */
+  LMC_EPROX_GAMMA = 10,             /* prox.py:60  params: omega, kappa         */
+  LMC_EPROX_CHI = 11,               /* prox.py:64  params: kappa                */
+  LMC_EPROX_UNIFORM = 12,           /* prox.py:68  params: omega                */
+  LMC_EPROX_TRIANGULAR = 13,        /* prox.py:78  params: omega1, omega2       */
+  LMC_EPROX_LAPLACE_CONJ = 14       /* prox.py:9 applied to prox_laplace; params: gamma */
+} lmc_eprox_kind;
+int lmc_prox_elementwise(int32_t kind, const float* x_dev, float* out_dev, int64_t n,
+                         const float* params_host, int32_t n_params, void* stream);
+
+/* ---- MYULA sampler (replaces algs.MoreauYosidaUnadjustedLangevin, algs.py:477-587) --- */
+
+typedef struct lmc_sampler lmc_sampler; /* opaque */
+
+typedef struct lmc_myula_config {
+  uint32_t struct_size;     /* = sizeof(lmc_myula_config) */
+  lmc_problem problem;
+  int32_t n_chains;         /* chains resident on this GPU */
+  int64_t chain_offset;     /* global id of local chain 0 (keys the RNG; sharding-invariant noise) */
+  float tau, gamma, epsg;   /* step, Moreau smoothing, scaling of g (algs.py:477-478) */
+  uint64_t seed;
+  int32_t noise_mode;       /* lmc_noise_mode */
+  /* posterior moments: sum / sum of squares over chains and kept iterations (generalises the
+   * mean over iterates at prox_lmc_deconv.py:474 to many chains, burn-in and thinning) */
+  int32_t moments;          /* 0 = off */
+  int32_t burn_in;          /* iterations (0-based index < burn_in) excluded */
+  int32_t thin;             /* keep every thin-th iteration after burn-in (>= 1) */
+} lmc_myula_config;
+
+int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out);
+void lmc_sampler_destroy(lmc_sampler* s);
+
+/* x_dev: [n_chains][H][W].  x0 of algs.py:559 (copied). */
+int lmc_sampler_set_state(lmc_sampler* s, const float* x_dev, void* stream);
+int lmc_sampler_get_state(lmc_sampler* s, float* x_dev, void* stream);
+/* Run n_iters iterations of algs.py:564-570 on every chain.  noise_dev is
+ * [n_iters][n_chains][H][W] when noise_mode == LMC_NOISE_INJECTED, else NULL. */
+int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, void* stream);
+/* iteration counter (number of completed iterations since creation / last set_iteration) */
+int64_t lmc_sampler_iteration(const lmc_sampler* s);
+int lmc_sampler_set_iteration(lmc_sampler* s, int64_t it);
+
+/* sum_dev, sumsq_dev: [H][W] double (device).  count = samples accumulated (chains*kept its). */
+int lmc_sampler_get_moments(lmc_sampler* s, double* sum_dev, double* sumsq_dev, uint64_t* count, void* stream);
+int lmc_sampler_reset_moments(lmc_sampler* s, void* stream);
+/* per-chain energies f(x_c), g(x_c) of the current state (device double [n_chains]) */
+int lmc_sampler_energies(lmc_sampler* s, double* f_out_dev, double* g_out_dev, void* stream);
+/* the noise field xi[n_chains][H][W] the sampler draws at `iteration` (parity rung R3) */
+int lmc_sampler_noise(lmc_sampler* s, int64_t iteration, float* out_dev, void* stream);
+/* HIP-event timing of the step kernels launched by the LAST lmc_sampler_step call on its stream:
+ * total milliseconds and number of step-kernel launches (bench.py's roofline leg). */
+int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_launches);
+/* name of the step kernel variant selected for this configuration (for profiles/) */
+const char* lmc_sampler_kernel_name(const lmc_sampler* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMC_ATOMI_H */

@@ -1,0 +1,16 @@
+"""lmc_atomi_amd -- MI355X-native Langevin-Monte-Carlo inner loop (drop-in for the hot path of
+192459/lmc-atomi): hand-written HIP kernels for gfx950 behind a C ABI (include/lmc_atomi.h),
+reached from Python through ctypes.  No CPU fallback: the package raises if liblmc_atomi.so
+is missing or no GPU is present."""
+from . import _capi
+from ._capi import LMCError
+from .operators import Convolve2D, Diagonal, Gradient, Identity, LinearOperator
+from .proximal import L1, L2, L21, TV, ProxOperator, fgp_betas
+from .algs import (MYULAResult, MYULASampler, MoreauYosidaUnadjustedLangevin, mean_var_from_moments)
+
+__all__ = [
+    "LMCError", "Convolve2D", "Diagonal", "Gradient", "Identity", "LinearOperator",
+    "L1", "L2", "L21", "TV", "ProxOperator", "fgp_betas",
+    "MYULASampler", "MYULAResult", "MoreauYosidaUnadjustedLangevin", "mean_var_from_moments",
+]
+__version__ = "0.1.0"

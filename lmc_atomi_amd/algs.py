@@ -1,0 +1,270 @@
+"""Sampler entry points -- drop-ins for the reference's ``algs.py``.
+
+``MoreauYosidaUnadjustedLangevin`` keeps the reference signature (algs.py:477-478) and return
+value (``ndarray (niter, n)`` of all iterates) for one chain, and adds keyword-only extensions
+for what the reference lacks: many chains per GPU, sharding-invariant counter-based noise,
+posterior moments with burn-in / thinning, per-chain energy diagnostics.
+
+The per-iteration update runs entirely in hand-written HIP kernels behind the C ABI
+(include/lmc_atomi.h); torch tensors are HBM containers only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+from numpy.random import default_rng
+
+from . import _capi, _dev
+from .proximal import _Problem
+
+
+def _prior_descriptor(proxg):
+    if proxg is None:
+        return {"prior_kind": _capi.PRIOR_NONE}
+    fn = getattr(proxg, "prior_descriptor", None)
+    if fn is None:
+        raise NotImplementedError(
+            f"{type(proxg).__name__} has no device functor (prior_descriptor()); new proxes are added as "
+            "functors compiled into liblmc_atomi -- there is no CPU fallback")
+    return fn()
+
+
+def _data_descriptor(proxf):
+    if proxf is None:
+        return {"data_kind": _capi.DATA_NONE}
+    fn = getattr(proxf, "descriptor", None)
+    if fn is None:
+        raise NotImplementedError(f"{type(proxf).__name__} has no device functor (descriptor())")
+    return fn()
+
+
+class MYULASampler:
+    """Many-chain MYULA on one GPU: owns an ``lmc_sampler`` handle.
+
+    State layout in HBM: ``[n_chains, H, W]`` fp32.  ``chain_offset`` is the global id of local
+    chain 0; the noise of a chain depends only on (seed, iteration, global chain id, pixel), so
+    any sharding of the chains over GPUs reproduces the same trajectories.
+    """
+
+    def __init__(self, proxf, proxg, dims, n_chains=1, tau=None, gamma=0.1, epsg=1.0, seed=0,
+                 chain_offset=0, noise="philox", moments=False, burn_in=0, thin=1, device=None):
+        if tau is None:
+            raise NotImplementedError("tau=None (backtracking) is not implemented by the reference loop either")
+        self.dims = (int(dims[0]), int(dims[1]))
+        self.n_chains = int(n_chains)
+        self.device = _dev.device(device)
+        self.proxf, self.proxg = proxf, proxg
+        self._problem = _Problem(self.dims, _data_descriptor(proxf), _prior_descriptor(proxg), self.device)
+        cfg = _capi.lmc_myula_config()
+        cfg.struct_size = C.sizeof(_capi.lmc_myula_config)
+        cfg.problem = self._problem.c
+        cfg.n_chains = self.n_chains
+        cfg.chain_offset = int(chain_offset)
+        cfg.tau, cfg.gamma, cfg.epsg = float(tau), float(gamma), float(epsg)
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.noise_mode = {"philox": _capi.NOISE_PHILOX, "injected": _capi.NOISE_INJECTED, "none": _capi.NOISE_NONE}[noise]
+        cfg.moments = 1 if moments else 0
+        cfg.burn_in = int(burn_in)
+        cfg.thin = int(thin)
+        self.noise_mode = noise
+        self.moments_on = bool(moments)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _capi.check(_dev.lib().lmc_myula_create(C.byref(cfg), C.byref(self._h)))
+
+    # -- lifetime ------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _dev.lib().lmc_sampler_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- state ---------------------------------------------------------------------------
+    @property
+    def shape(self):
+        return (self.n_chains,) + self.dims
+
+    def set_state(self, x):
+        xt = _dev.to_dev(x, self.device)
+        n = self.dims[0] * self.dims[1]
+        if xt.numel() == n:                       # one image: broadcast to every chain (x0 of algs.py:559)
+            xt = xt.reshape(1, *self.dims).expand(self.shape).contiguous()
+        if xt.numel() != self.n_chains * n:
+            raise ValueError(f"state of shape {tuple(xt.shape)} does not match {self.shape}")
+        _capi.check(_dev.lib().lmc_sampler_set_state(self._h, _dev.ptr(xt), _dev.stream_ptr()))
+        torch.cuda.current_stream().synchronize()  # xt may be a temporary
+
+    def get_state(self, out=None):
+        if out is None:
+            out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        _capi.check(_dev.lib().lmc_sampler_get_state(self._h, _dev.ptr(out), _dev.stream_ptr()))
+        return out
+
+    @property
+    def iteration(self):
+        return int(_dev.lib().lmc_sampler_iteration(self._h))
+
+    @iteration.setter
+    def iteration(self, it):
+        _capi.check(_dev.lib().lmc_sampler_set_iteration(self._h, int(it)))
+
+    # -- hot loop ------------------------------------------------------------------------
+    def step(self, n_iters=1, noise=None):
+        """Run ``n_iters`` iterations of algs.py:564-570 on every chain.  ``noise`` (only with
+        noise='injected'): ``[n_iters, n_chains, H, W]``."""
+        nt = None
+        if noise is not None:
+            nt = _dev.to_dev(noise, self.device)
+            if nt.numel() != n_iters * self.n_chains * self.dims[0] * self.dims[1]:
+                raise ValueError("noise must have shape [n_iters, n_chains, H, W]")
+        _capi.check(_dev.lib().lmc_sampler_step(self._h, int(n_iters), _dev.ptr(nt), _dev.stream_ptr()))
+        if nt is not None:
+            torch.cuda.current_stream().synchronize()
+
+    def last_step_timing(self):
+        ms, n = C.c_float(), C.c_int32()
+        _capi.check(_dev.lib().lmc_sampler_last_step_timing(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    @property
+    def kernel_name(self):
+        return _dev.lib().lmc_sampler_kernel_name(self._h).decode()
+
+    # -- diagnostics ---------------------------------------------------------------------
+    def energies(self):
+        """Per-chain ``f(x_c)``, ``g(x_c)`` (float64 tensors in HBM) -- the energy log of algs.py:578-582."""
+        f = torch.empty(self.n_chains, dtype=torch.float64, device=self.device)
+        g = torch.empty(self.n_chains, dtype=torch.float64, device=self.device)
+        _capi.check(_dev.lib().lmc_sampler_energies(self._h, _dev.ptr(f), _dev.ptr(g), _dev.stream_ptr()))
+        return f, g
+
+    def noise_field(self, iteration):
+        out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        _capi.check(_dev.lib().lmc_sampler_noise(self._h, int(iteration), _dev.ptr(out), _dev.stream_ptr()))
+        return out
+
+    def moments(self):
+        """(sum [H,W] f64, sumsq [H,W] f64, count) over chains and kept iterations."""
+        s1 = torch.empty(self.dims, dtype=torch.float64, device=self.device)
+        s2 = torch.empty(self.dims, dtype=torch.float64, device=self.device)
+        cnt = C.c_uint64()
+        _capi.check(_dev.lib().lmc_sampler_get_moments(self._h, _dev.ptr(s1), _dev.ptr(s2), C.byref(cnt),
+                                                       _dev.stream_ptr()))
+        return s1, s2, int(cnt.value)
+
+    def reset_moments(self):
+        _capi.check(_dev.lib().lmc_sampler_reset_moments(self._h, _dev.stream_ptr()))
+
+
+def mean_var_from_moments(s1, s2, count):
+    """Posterior mean and pixel-wise variance from accumulated sums (any array type)."""
+    mean = s1 / count
+    var = s2 / count - mean * mean
+    return mean, var
+
+
+class MYULAResult:
+    """Return value of the many-chain form of :func:`MoreauYosidaUnadjustedLangevin`."""
+
+    def __init__(self, state, mean, var, count, energy_f, energy_g, elapsed):
+        self.state, self.mean, self.var, self.count = state, mean, var, count
+        self.energy_f, self.energy_g, self.elapsed = energy_f, energy_g, elapsed
+
+
+def MoreauYosidaUnadjustedLangevin(proxf, proxg, x0, tau=None, gamma=.1, epsg=1., niter=10, seed=0,
+                                   callback=None, show=False, *, n_chains=None, dims=None, rng="philox",
+                                   chain_offset=0, burn_in=0, thin=1, device=None):
+    r"""Moreau--Yosida Unadjusted Langevin algorithm (MYULA) -- drop-in for algs.py:477-587.
+
+    .. math::
+        x^{k+1} = (1-\tau/\gamma)x^k - \tau\nabla f(x^k) + (\tau/\gamma)\,prox_{\gamma\epsilon g}(x^k)
+                  + \sqrt{2\tau}\,\xi^k
+
+    Reference form (``n_chains is None``): one chain, returns ``np.ndarray (niter, n)`` holding
+    every iterate, ``callback(x)`` after every iteration, ``show`` prints the reference's log.
+    ``rng='pcg64'`` draws the noise exactly as the reference does (``default_rng(seed)``, one
+    ``standard_normal(n)`` per iteration, algs.py:561,565) and injects it, so the trajectory
+    equals the reference's to fp32 rounding; ``rng='philox'`` (default) draws on the GPU.
+
+    Many-chain form (``n_chains=C``): runs C chains from ``x0`` (one image or ``[C,H,W]``), keeps
+    no iterates, returns a :class:`MYULAResult` (final states, posterior mean / variance over
+    chains and kept iterations, per-chain energies).
+    """
+    if dims is None:
+        dims = getattr(proxf, "dims", None) or getattr(proxg, "dims", None)
+    if dims is None:
+        raise ValueError("image shape unknown: pass dims=(ny, nx)")
+    many = n_chains is not None
+    C_ = int(n_chains) if many else 1
+    n = int(dims[0]) * int(dims[1])
+    if rng not in ("philox", "pcg64"):
+        raise ValueError("rng must be 'philox' or 'pcg64'")
+    if rng == "pcg64" and C_ != 1:
+        raise ValueError("rng='pcg64' reproduces the reference's single chain; use n_chains=None")
+    smp = MYULASampler(proxf, proxg, dims, n_chains=C_, tau=tau, gamma=gamma, epsg=epsg, seed=seed,
+                       chain_offset=chain_offset, noise="injected" if rng == "pcg64" else "philox",
+                       moments=many, burn_in=burn_in, thin=thin, device=device)
+    try:
+        smp.set_state(x0)
+        tstart = time.time()
+        if show:
+            print('Moreau--Yosida Unadjusted Langevin (lmc_atomi_amd / HIP)\n'
+                  '---------------------------------------------------------\n'
+                  'Proximal operator (f): %s\nProximal operator (g): %s\n'
+                  'tau = %s\tgamma=%10e\nepsg = %s\tniter = %d\tchains = %d\n' %
+                  (type(proxf), type(proxg), str(tau), gamma, str(epsg), niter, C_))
+            print('   Itn       x[0]          f           g     J = f + eps*g')
+        if not many:
+            samples = np.empty((niter, n), dtype=np.asarray(x0).dtype if not isinstance(x0, torch.Tensor) else np.float32)
+            host_rng = default_rng(seed) if rng == "pcg64" else None
+            buf = torch.empty(smp.shape, dtype=torch.float32, device=smp.device)
+            for it in range(niter):
+                if host_rng is not None:
+                    xi = host_rng.standard_normal(n)                  # algs.py:565
+                    smp.step(1, noise=xi.reshape(1, 1, *smp.dims))
+                else:
+                    smp.step(1)
+                smp.get_state(buf)
+                xk = buf.reshape(-1).cpu().numpy()
+                samples[it] = xk
+                if callback is not None:
+                    callback(samples[it])
+                if show and (it < 10 or niter - it < 10 or it % max(niter // 10, 1) == 0):
+                    f, g = smp.energies()
+                    pf, pg = float(f[0]), float(g[0])
+                    print('%6g  %12.5e  %10.3e  %10.3e  %10.3e' % (it + 1, samples[it][0], pf, pg, pf + epsg * pg))
+            if show:
+                print('\nTotal time (s) = %.2f' % (time.time() - tstart))
+                print('---------------------------------------------------------\n')
+            return samples
+        # many chains: no iterates kept
+        done = 0
+        while done < niter:
+            chunk = niter - done if (callback is None and not show) else 1
+            smp.step(chunk)
+            done += chunk
+            if callback is not None:
+                callback(smp.get_state())
+            if show and (done <= 10 or niter - done < 10 or (done - 1) % max(niter // 10, 1) == 0):
+                f, g = smp.energies()
+                x00 = float(smp.get_state()[0, 0, 0])
+                print('%6g  %12.5e  %10.3e  %10.3e  %10.3e' % (done, x00, float(f.mean()), float(g.mean()),
+                                                              float((f + epsg * g).mean())))
+        s1, s2, cnt = smp.moments()
+        f, g = smp.energies()
+        state = smp.get_state()
+        torch.cuda.current_stream().synchronize()
+        mean, var = mean_var_from_moments(s1, s2, max(cnt, 1))
+        return MYULAResult(state, mean, var, cnt, f, g, time.time() - tstart)
+    finally:
+        smp.close()

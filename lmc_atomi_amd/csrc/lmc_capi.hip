@@ -1,0 +1,436 @@
+// extern "C" boundary of liblmc_atomi.so (see include/lmc_atomi.h).  Argument checks happen
+// HERE, on the host, before any kernel sees a pointer or a shape.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "lmc_launch.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(LMC_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+int fill_taps(lmc::BlurTaps& T, const float* h, int kh, int kw, int oy, int ox) {
+  if (!h) return fail(LMC_E_INVALID, "blur kernel pointer is NULL");
+  if (kh < 1 || kw < 1 || kh > lmc::kMaxBlur || kw > lmc::kMaxBlur)
+    return fail(LMC_E_UNSUPPORTED, "blur kernel %dx%d outside 1..%d", kh, kw, lmc::kMaxBlur);
+  if (oy < 0 || oy >= kh || ox < 0 || ox >= kw) return fail(LMC_E_INVALID, "blur offset (%d,%d) outside kernel", oy, ox);
+  T.kh = kh; T.kw = kw; T.oy = oy; T.ox = ox;
+  std::memset(T.h, 0, sizeof T.h);
+  std::memcpy(T.h, h, sizeof(float) * kh * kw);
+  return LMC_OK;
+}
+
+// default momentum table: t_k = (1 + sqrt(4 t_{k-1}^2))/2 (pyproximal.TV / UNLocBoX), beta_k = (t_{k-1}-1)/t_k
+void default_betas(float* b, int n) {
+  double t = 1.0;
+  for (int k = 0; k < n; ++k) {
+    const double tn = (1.0 + std::sqrt(4.0 * t * t)) / 2.0;
+    b[k] = (float)((t - 1.0) / tn);
+    t = tn;
+  }
+}
+
+// Validated, self-contained copy of an lmc_problem.
+struct Problem {
+  int H = 0, W = 0;
+  int data_kind = 0;
+  float sigma_f = 0.f;
+  const float* y = nullptr;
+  const float* mask = nullptr;
+  lmc::BlurTaps taps{};
+  int prior_kind = 0;
+  float prior_sigma = 0.f;
+  int tv_niter = 0;
+  float tv_step = 0.125f;
+  float betas[lmc::kMaxTvIters] = {};
+};
+
+int load_problem(const lmc_problem* p, Problem& q) {
+  if (!p) return fail(LMC_E_INVALID, "lmc_problem is NULL");
+  if (p->struct_size != sizeof(lmc_problem))
+    return fail(LMC_E_INVALID, "lmc_problem.struct_size %u != %zu (ABI mismatch)", p->struct_size, sizeof(lmc_problem));
+  if (p->H < 1 || p->W < 1 || (int64_t)p->H * p->W > (int64_t)1 << 30) return fail(LMC_E_INVALID, "bad image size %dx%d", p->H, p->W);
+  q.H = p->H; q.W = p->W;
+  q.data_kind = p->data_kind;
+  q.sigma_f = p->sigma_f;
+  q.y = p->y_dev;
+  q.mask = p->mask_dev;
+  switch (p->data_kind) {
+    case LMC_DATA_NONE: break;
+    case LMC_DATA_IDENTITY:
+      if (!p->y_dev) return fail(LMC_E_INVALID, "data term needs y_dev");
+      break;
+    case LMC_DATA_MASK:
+      if (!p->y_dev || !p->mask_dev) return fail(LMC_E_INVALID, "mask data term needs y_dev and mask_dev");
+      break;
+    case LMC_DATA_BLUR: {
+      if (!p->y_dev) return fail(LMC_E_INVALID, "data term needs y_dev");
+      int rc = fill_taps(q.taps, p->h_host, p->kh, p->kw, p->oy, p->ox);
+      if (rc) return rc;
+      break;
+    }
+    default: return fail(LMC_E_INVALID, "unknown data_kind %d", p->data_kind);
+  }
+  q.prior_kind = p->prior_kind;
+  q.prior_sigma = p->prior_sigma;
+  switch (p->prior_kind) {
+    case LMC_PRIOR_NONE: case LMC_PRIOR_L2: case LMC_PRIOR_L1: break;
+    case LMC_PRIOR_TV_ISO:
+      if (p->tv_niter < 1 || p->tv_niter > lmc::kMaxTvIters)
+        return fail(LMC_E_UNSUPPORTED, "tv_niter %d outside 1..%d", p->tv_niter, lmc::kMaxTvIters);
+      q.tv_niter = p->tv_niter;
+      q.tv_step = p->tv_step > 0.f ? p->tv_step : 0.125f;
+      if (p->tv_betas_host) std::memcpy(q.betas, p->tv_betas_host, sizeof(float) * p->tv_niter);
+      else default_betas(q.betas, p->tv_niter);
+      break;
+    default: return fail(LMC_E_INVALID, "unknown prior_kind %d", p->prior_kind);
+  }
+  if (p->prior_kind != LMC_PRIOR_NONE && !(p->prior_sigma >= 0.f)) return fail(LMC_E_INVALID, "prior_sigma must be >= 0");
+  return LMC_OK;
+}
+
+// StepArgs for: out = a*x - t*grad f + b*prox_{pt*g}(x) + s*xi
+int make_step_args(const Problem& q, float a, float t, float b, float pt, float s, lmc::StepArgs& A) {
+  std::memset(&A, 0, sizeof A);
+  A.H = q.H; A.W = q.W;
+  A.data_kind = (t == 0.f) ? LMC_DATA_NONE : q.data_kind;   // skip the stencil work if its weight is zero
+  A.sigma_f = q.sigma_f;
+  A.y = q.y; A.mask = q.mask;
+  A.blur = q.taps;
+  A.prior_kind = (b == 0.f) ? LMC_PRIOR_NONE : q.prior_kind;
+  if (A.prior_kind == LMC_PRIOR_L2) A.prior_p0 = 1.f / (1.f + pt * q.prior_sigma);
+  if (A.prior_kind == LMC_PRIOR_L1) A.prior_p0 = pt * q.prior_sigma;
+  if (A.prior_kind == LMC_PRIOR_TV_ISO) {
+    const float gam = pt * q.prior_sigma;
+    if (!(gam > 0.f)) return fail(LMC_E_INVALID, "TV prox parameter must be > 0 (got %g)", (double)gam);
+    A.tv.niter = q.tv_niter;
+    A.tv.gamma = gam;
+    A.tv.c = q.tv_step / gam;
+    std::memcpy(A.tv.betas, q.betas, sizeof(float) * q.tv_niter);
+  }
+  A.a = a; A.t = t; A.b = b; A.s = s;
+  A.noise_mode = LMC_NOISE_NONE;
+  return LMC_OK;
+}
+
+}  // namespace
+
+struct lmc_sampler {
+  Problem prob;
+  int C = 0;
+  int64_t chain_offset = 0;
+  float tau = 0, gamma = 0, epsg = 1;
+  uint64_t seed = 0;
+  int noise_mode = 0;
+  int moments = 0, burn_in = 0, thin = 1;
+  int64_t iteration = 0;
+  uint64_t count = 0;
+  float* x[2] = {nullptr, nullptr};
+  int cur = 0;
+  double* s1 = nullptr;
+  double* s2 = nullptr;
+  lmc::StepArgs base{};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  int last_launches = 0;
+  std::string kernel_name;
+};
+
+extern "C" {
+
+int lmc_version(void) { return LMC_ATOMI_ABI_VERSION; }
+
+const char* lmc_last_error(void) { return g_err.c_str(); }
+
+int lmc_device_info(int* device, int* n_cu, size_t* lds_bytes, size_t* hbm_bytes) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t pr;
+  HIP_TRY(hipGetDeviceProperties(&pr, dev));
+  if (device) *device = dev;
+  if (n_cu) *n_cu = pr.multiProcessorCount;
+  if (lds_bytes) *lds_bytes = pr.maxSharedMemoryPerMultiProcessor;
+  if (hbm_bytes) *hbm_bytes = pr.totalGlobalMem;
+  return LMC_OK;
+}
+
+int lmc_blur(const float* x_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W, const float* h_host, int32_t kh,
+             int32_t kw, int32_t oy, int32_t ox, int32_t adjoint, void* stream) {
+  if (!x_dev || !out_dev) return fail(LMC_E_INVALID, "NULL image pointer");
+  if (x_dev == out_dev) return fail(LMC_E_INVALID, "lmc_blur cannot run in place");
+  if (n_img < 1 || H < 1 || W < 1) return fail(LMC_E_INVALID, "bad shape n_img=%lld H=%d W=%d", (long long)n_img, H, W);
+  lmc::BlurTaps T;
+  int rc = fill_taps(T, h_host, kh, kw, oy, ox);
+  if (rc) return rc;
+  HIP_TRY(lmc::launch_blur(x_dev, out_dev, n_img, H, W, T, adjoint != 0, S(stream)));
+  return LMC_OK;
+}
+
+int lmc_gradient(const float* x_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W, void* stream) {
+  if (!x_dev || !out_dev || x_dev == out_dev) return fail(LMC_E_INVALID, "bad pointers");
+  if (n_img < 1 || H < 1 || W < 1) return fail(LMC_E_INVALID, "bad shape");
+  HIP_TRY(lmc::launch_gradient(x_dev, out_dev, n_img, H, W, false, S(stream)));
+  return LMC_OK;
+}
+
+int lmc_gradient_adjoint(const float* y_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W, void* stream) {
+  if (!y_dev || !out_dev || y_dev == out_dev) return fail(LMC_E_INVALID, "bad pointers");
+  if (n_img < 1 || H < 1 || W < 1) return fail(LMC_E_INVALID, "bad shape");
+  HIP_TRY(lmc::launch_gradient(y_dev, out_dev, n_img, H, W, true, S(stream)));
+  return LMC_OK;
+}
+
+int lmc_fused_eval(const lmc_problem* prob, const float* x_dev, float* out_dev, int64_t n_img, float a, float t, float b,
+                   float pt, void* stream) {
+  Problem q;
+  int rc = load_problem(prob, q);
+  if (rc) return rc;
+  if (!x_dev || !out_dev || x_dev == out_dev) return fail(LMC_E_INVALID, "bad pointers (in-place not allowed)");
+  if (n_img < 1 || n_img > (1 << 24)) return fail(LMC_E_INVALID, "bad n_img %lld", (long long)n_img);
+  lmc::StepArgs A;
+  rc = make_step_args(q, a, t, b, pt, 0.f, A);
+  if (rc) return rc;
+  A.C = (int)n_img;
+  A.x_in = x_dev;
+  A.x_out = out_dev;
+  hipError_t e = lmc::launch_step_tile(A, S(stream));
+  if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no tile plan fits LDS for this halo");
+  HIP_TRY(e);
+  return LMC_OK;
+}
+
+static lmc::EnergyArgs energy_args(const Problem& q) {
+  lmc::EnergyArgs E;
+  E.H = q.H; E.W = q.W; E.data_kind = q.data_kind; E.sigma_f = q.sigma_f; E.y = q.y; E.mask = q.mask;
+  E.blur = q.taps; E.prior_kind = q.prior_kind; E.prior_sigma = q.prior_sigma;
+  return E;
+}
+
+int lmc_energies(const lmc_problem* prob, const float* x_dev, int64_t n_img, double* f_out_dev, double* g_out_dev,
+                 void* stream) {
+  Problem q;
+  int rc = load_problem(prob, q);
+  if (rc) return rc;
+  if (!x_dev || n_img < 1) return fail(LMC_E_INVALID, "bad arguments");
+  HIP_TRY(lmc::launch_energies(x_dev, n_img, energy_args(q), f_out_dev, g_out_dev, S(stream)));
+  return LMC_OK;
+}
+
+int lmc_dual_project(const float* y_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W, float radius,
+                     int32_t isotropic, void* stream) {
+  if (!y_dev || !out_dev) return fail(LMC_E_INVALID, "NULL pointer");
+  if (n_img < 1 || H < 1 || W < 1 || !(radius > 0.f)) return fail(LMC_E_INVALID, "bad shape or radius");
+  HIP_TRY(lmc::launch_dual_project(y_dev, out_dev, n_img, H, W, radius, isotropic, S(stream)));
+  return LMC_OK;
+}
+
+int lmc_prox_elementwise(int32_t kind, const float* x_dev, float* out_dev, int64_t n, const float* params_host,
+                         int32_t n_params, void* stream) {
+  static const int need[] = {1, 2, 1, 1, 1, 1, 1, 2, 1, 1, 2, 1, 1, 2, 1};
+  if (kind < 0 || kind > LMC_EPROX_LAPLACE_CONJ) return fail(LMC_E_INVALID, "unknown elementwise prox %d", kind);
+  if (!x_dev || !out_dev || n < 1) return fail(LMC_E_INVALID, "bad arguments");
+  if (n_params != need[kind] || !params_host)
+    return fail(LMC_E_INVALID, "elementwise prox %d takes %d parameter(s), got %d", kind, need[kind], n_params);
+  const float p0 = params_host[0], p1 = n_params > 1 ? params_host[1] : 0.f;
+  HIP_TRY(lmc::launch_eprox(kind, x_dev, out_dev, n, p0, p1, S(stream)));
+  return LMC_OK;
+}
+
+// ---- sampler ---------------------------------------------------------------------------------
+
+int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
+  if (!cfg || !out) return fail(LMC_E_INVALID, "NULL argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(lmc_myula_config))
+    return fail(LMC_E_INVALID, "lmc_myula_config.struct_size %u != %zu (ABI mismatch)", cfg->struct_size, sizeof(lmc_myula_config));
+  if (cfg->n_chains < 1) return fail(LMC_E_INVALID, "n_chains must be >= 1");
+  if (cfg->chain_offset < 0 || cfg->chain_offset + cfg->n_chains > 0xFFFFFFFFLL)
+    return fail(LMC_E_INVALID, "global chain ids must fit 32 bits");
+  if (!(cfg->tau > 0.f) || !(cfg->gamma > 0.f)) return fail(LMC_E_INVALID, "tau and gamma must be > 0");
+  if (cfg->noise_mode < LMC_NOISE_PHILOX || cfg->noise_mode > LMC_NOISE_NONE) return fail(LMC_E_INVALID, "bad noise_mode");
+  if (cfg->moments && cfg->thin < 1) return fail(LMC_E_INVALID, "thin must be >= 1");
+  lmc_sampler* s = new (std::nothrow) lmc_sampler();
+  if (!s) return fail(LMC_E_NOMEM, "host allocation failed");
+  int rc = load_problem(&cfg->problem, s->prob);
+  if (rc) { delete s; return rc; }
+  s->C = cfg->n_chains;
+  s->chain_offset = cfg->chain_offset;
+  s->tau = cfg->tau; s->gamma = cfg->gamma; s->epsg = cfg->epsg;
+  s->seed = cfg->seed;
+  s->noise_mode = cfg->noise_mode;
+  s->moments = cfg->moments; s->burn_in = cfg->burn_in; s->thin = cfg->thin < 1 ? 1 : cfg->thin;
+  // x <- (1 - tau/gamma) x - tau grad f(x) + (tau/gamma) prox_{epsg*gamma*g}(x) + sqrt(2 tau) xi   (algs.py:569)
+  rc = make_step_args(s->prob, 1.f - s->tau / s->gamma, s->tau, s->tau / s->gamma, s->epsg * s->gamma,
+                      std::sqrt(2.f * s->tau), s->base);
+  if (rc) { delete s; return rc; }
+  s->base.C = s->C;
+  s->base.noise_mode = s->noise_mode;
+  s->base.key0 = (uint32_t)(s->seed & 0xFFFFFFFFu);
+  s->base.key1 = (uint32_t)(s->seed >> 32);
+  s->base.chain_offset = (uint32_t)s->chain_offset;
+  const size_t nbytes = sizeof(float) * (size_t)s->C * s->prob.H * s->prob.W;
+  hipError_t e = hipMalloc(&s->x[0], nbytes);
+  if (e == hipSuccess) e = hipMalloc(&s->x[1], nbytes);
+  if (e == hipSuccess) e = hipMemset(s->x[0], 0, nbytes);
+  if (e == hipSuccess && s->moments) {
+    const size_t mb = sizeof(double) * (size_t)s->prob.H * s->prob.W;
+    e = hipMalloc(&s->s1, mb);
+    if (e == hipSuccess) e = hipMalloc(&s->s2, mb);
+    if (e == hipSuccess) e = hipMemset(s->s1, 0, mb);
+    if (e == hipSuccess) e = hipMemset(s->s2, 0, mb);
+  }
+  if (e == hipSuccess) e = hipEventCreate(&s->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+  if (e != hipSuccess) {
+    rc = fail(e == hipErrorOutOfMemory ? LMC_E_NOMEM : LMC_E_HIP, "sampler allocation failed: %s", hipGetErrorString(e));
+    lmc_sampler_destroy(s);
+    return rc;
+  }
+  s->kernel_name = s->prob.prior_kind == LMC_PRIOR_TV_ISO ? "myula_step_tile_kernel<NP,true>" : "myula_step_tile_kernel<NP,false>";
+  *out = s;
+  return LMC_OK;
+}
+
+void lmc_sampler_destroy(lmc_sampler* s) {
+  if (!s) return;
+  if (s->x[0]) (void)hipFree(s->x[0]);
+  if (s->x[1]) (void)hipFree(s->x[1]);
+  if (s->s1) (void)hipFree(s->s1);
+  if (s->s2) (void)hipFree(s->s2);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  delete s;
+}
+
+int lmc_sampler_set_state(lmc_sampler* s, const float* x_dev, void* stream) {
+  if (!s || !x_dev) return fail(LMC_E_INVALID, "NULL argument");
+  const size_t nbytes = sizeof(float) * (size_t)s->C * s->prob.H * s->prob.W;
+  HIP_TRY(hipMemcpyAsync(s->x[s->cur], x_dev, nbytes, hipMemcpyDeviceToDevice, S(stream)));
+  return LMC_OK;
+}
+
+int lmc_sampler_get_state(lmc_sampler* s, float* x_dev, void* stream) {
+  if (!s || !x_dev) return fail(LMC_E_INVALID, "NULL argument");
+  const size_t nbytes = sizeof(float) * (size_t)s->C * s->prob.H * s->prob.W;
+  HIP_TRY(hipMemcpyAsync(x_dev, s->x[s->cur], nbytes, hipMemcpyDeviceToDevice, S(stream)));
+  return LMC_OK;
+}
+
+int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, void* stream) {
+  if (!s) return fail(LMC_E_INVALID, "NULL sampler");
+  if (n_iters < 0) return fail(LMC_E_INVALID, "n_iters < 0");
+  if (s->noise_mode == LMC_NOISE_INJECTED && !noise_dev && n_iters > 0)
+    return fail(LMC_E_INVALID, "noise_mode is INJECTED but noise_dev is NULL");
+  if (s->noise_mode != LMC_NOISE_INJECTED && noise_dev)
+    return fail(LMC_E_INVALID, "noise_dev given but noise_mode is not INJECTED");
+  if (s->iteration + n_iters > 0xFFFFFFFFLL) return fail(LMC_E_STATE, "iteration counter would exceed 32 bits");
+  hipStream_t st = S(stream);
+  const size_t per_iter = (size_t)s->C * s->prob.H * s->prob.W;
+  s->timed = false;
+  s->last_launches = 0;
+  if (n_iters == 0) return LMC_OK;
+  HIP_TRY(hipEventRecord(s->ev0, st));
+  // The event pair brackets ONLY step kernels when moments are off; with moments on the
+  // interleaved reduction launches are inside the bracket too (reported as such by the caller).
+  for (int k = 0; k < n_iters; ++k) {
+    lmc::StepArgs A = s->base;
+    A.x_in = s->x[s->cur];
+    A.x_out = s->x[s->cur ^ 1];
+    A.iteration = (uint32_t)s->iteration;
+    A.noise = noise_dev ? noise_dev + (size_t)k * per_iter : nullptr;
+    hipError_t e = lmc::launch_step_tile(A, st);
+    if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no tile plan fits LDS for this halo");
+    HIP_TRY(e);
+    s->cur ^= 1;
+    if (s->moments && s->iteration >= s->burn_in && (s->iteration - s->burn_in) % s->thin == 0) {
+      HIP_TRY(lmc::launch_moments(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st));
+      s->count += (uint64_t)s->C;
+    }
+    ++s->iteration;
+    ++s->last_launches;
+  }
+  HIP_TRY(hipEventRecord(s->ev1, st));
+  s->timed = true;
+  return LMC_OK;
+}
+
+int64_t lmc_sampler_iteration(const lmc_sampler* s) { return s ? s->iteration : -1; }
+
+int lmc_sampler_set_iteration(lmc_sampler* s, int64_t it) {
+  if (!s || it < 0 || it > 0xFFFFFFFFLL) return fail(LMC_E_INVALID, "bad iteration");
+  s->iteration = it;
+  return LMC_OK;
+}
+
+int lmc_sampler_get_moments(lmc_sampler* s, double* sum_dev, double* sumsq_dev, uint64_t* count, void* stream) {
+  if (!s) return fail(LMC_E_INVALID, "NULL sampler");
+  if (!s->moments) return fail(LMC_E_STATE, "sampler was created with moments = 0");
+  const size_t mb = sizeof(double) * (size_t)s->prob.H * s->prob.W;
+  if (sum_dev) HIP_TRY(hipMemcpyAsync(sum_dev, s->s1, mb, hipMemcpyDeviceToDevice, S(stream)));
+  if (sumsq_dev) HIP_TRY(hipMemcpyAsync(sumsq_dev, s->s2, mb, hipMemcpyDeviceToDevice, S(stream)));
+  HIP_TRY(hipStreamSynchronize(S(stream)));
+  if (count) *count = s->count;
+  return LMC_OK;
+}
+
+int lmc_sampler_reset_moments(lmc_sampler* s, void* stream) {
+  if (!s) return fail(LMC_E_INVALID, "NULL sampler");
+  if (!s->moments) return fail(LMC_E_STATE, "sampler was created with moments = 0");
+  const size_t mb = sizeof(double) * (size_t)s->prob.H * s->prob.W;
+  HIP_TRY(hipMemsetAsync(s->s1, 0, mb, S(stream)));
+  HIP_TRY(hipMemsetAsync(s->s2, 0, mb, S(stream)));
+  s->count = 0;
+  return LMC_OK;
+}
+
+int lmc_sampler_energies(lmc_sampler* s, double* f_out_dev, double* g_out_dev, void* stream) {
+  if (!s) return fail(LMC_E_INVALID, "NULL sampler");
+  HIP_TRY(lmc::launch_energies(s->x[s->cur], s->C, energy_args(s->prob), f_out_dev, g_out_dev, S(stream)));
+  return LMC_OK;
+}
+
+int lmc_sampler_noise(lmc_sampler* s, int64_t iteration, float* out_dev, void* stream) {
+  if (!s || !out_dev) return fail(LMC_E_INVALID, "NULL argument");
+  if (iteration < 0 || iteration > 0xFFFFFFFFLL) return fail(LMC_E_INVALID, "bad iteration");
+  HIP_TRY(lmc::launch_noise(out_dev, s->C, s->prob.H, s->prob.W, s->base.key0, s->base.key1, (uint32_t)iteration,
+                            s->base.chain_offset, S(stream)));
+  return LMC_OK;
+}
+
+int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_launches) {
+  if (!s) return fail(LMC_E_INVALID, "NULL sampler");
+  if (!s->timed) return fail(LMC_E_STATE, "no timed lmc_sampler_step call to report");
+  HIP_TRY(hipEventSynchronize(s->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+  if (total_ms) *total_ms = ms;
+  if (n_launches) *n_launches = s->last_launches;
+  return LMC_OK;
+}
+
+const char* lmc_sampler_kernel_name(const lmc_sampler* s) { return s ? s->kernel_name.c_str() : ""; }
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+// Shared host/device declarations for liblmc_atomi (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "lmc_atomi.h"
+
+namespace lmc {
+
+constexpr int kMaxBlur = LMC_MAX_BLUR;
+constexpr int kMaxTvIters = LMC_MAX_TV_ITERS;
+constexpr int kWave = 64;  // CDNA4 wavefront
+
+// Blur taps live in the kernel-argument segment (scalar loads, uniform over the grid).
+struct BlurTaps {
+  int kh, kw, oy, ox;
+  float h[kMaxBlur * kMaxBlur];
+};
+
+struct TvIter {
+  int niter;
+  float gamma;   // prox parameter * prior_sigma
+  float c;       // dual step = tv_step / gamma
+  float betas[kMaxTvIters];
+};
+
+// out = a*x - t*grad f(x) + b*prox(x) + s*xi
+struct StepArgs {
+  int H, W, C;
+  int tiles_x, tiles_y, TH, TW, HL, PH, PW;
+  int data_kind;
+  float sigma_f;
+  const float* y;
+  const float* mask;
+  BlurTaps blur;
+  int prior_kind;
+  float prior_p0;     // L2: 1/(1+t*sigma) ; L1: threshold t*sigma
+  TvIter tv;
+  float a, t, b, s;
+  int noise_mode;
+  const float* noise;        // [C][H][W] of this iteration (injected)
+  uint32_t key0, key1;       // Philox key = seed
+  uint32_t iteration;        // Philox counter word 1
+  uint32_t chain_offset;     // global id of chain 0 (counter word 2 = chain_offset + c)
+  const float* x_in;
+  float* x_out;
+};
+
+constexpr uint32_t kPhiloxStream = 0x4C4D4301u;  // counter word 3
+
+}  // namespace lmc

@@ -1,0 +1,80 @@
+// Device-side building blocks: Philox4x32-10, Box-Muller, wave/block reductions.
+#pragma once
+#include "lmc_common.h"
+
+namespace lmc {
+
+// Philox4x32-10 (Salmon et al., SC'11).  One call -> 4 x uint32.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// uint32 -> (0,1]: u*2^-32 + 2^-33, one fma (v_cvt_f32_u32 rounds to nearest even).
+__device__ __forceinline__ float u01(uint32_t u) {
+  return fmaf((float)u, 0x1p-32f, 0x1p-33f);
+}
+
+// Two N(0,1) per uint32 pair: r = sqrt(-2 ln u_a); (r sin 2*pi*u_b, r cos 2*pi*u_b).
+__device__ __forceinline__ void box_muller(uint32_t ua, uint32_t ub, float& n0, float& n1) {
+  const float u1 = u01(ua), u2 = u01(ub);
+  const float r = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincospif(2.0f * u2, &sn, &cs);
+  n0 = r * sn;
+  n1 = r * cs;
+}
+
+// The 4 normals of quad (row>>2, col) of `chain` at `iteration`: rows 4q+0..3 of column col.
+__device__ __forceinline__ void quad_normals(uint32_t key0, uint32_t key1, uint32_t iteration,
+                                             uint32_t chain, uint32_t quad, float (&n)[4]) {
+  uint32_t o[4];
+  philox4x32_10(quad, iteration, chain, kPhiloxStream, key0, key1, o);
+  box_muller(o[0], o[1], n[0], n[1]);
+  box_muller(o[2], o[3], n[2], n[3]);
+}
+
+// 64-lane wavefront sum; result valid in lane 0.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+
+// Block sum via wave shuffles + one LDS slot per wave; result valid in thread 0.
+// `scratch` must hold blockDim.x/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
+  v = wave_sum(v);
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  double tot = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + kWave - 1) >> 6;
+    for (int i = 0; i < nw; ++i) tot += scratch[i];
+  }
+  __syncthreads();
+  return tot;
+}
+
+// Bijective XCD-aware remap: hardware deals consecutive block ids round-robin over the 8 XCDs;
+// give each XCD a contiguous range of logical ids so tiles of one chain share an L2.
+__device__ __forceinline__ int xcd_logical_block(int b, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = b & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+}  // namespace lmc

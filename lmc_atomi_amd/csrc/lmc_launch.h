@@ -1,0 +1,31 @@
+// Host-side launcher declarations (defined in lmc_step_*.hip / lmc_ops.hip).
+#pragma once
+#include "lmc_common.h"
+
+namespace lmc {
+
+struct EnergyArgs {
+  int H, W;
+  int data_kind;
+  float sigma_f;
+  const float* y;
+  const float* mask;
+  BlurTaps blur;
+  int prior_kind;
+  float prior_sigma;
+};
+
+hipError_t launch_step_tile(StepArgs a, hipStream_t st);
+hipError_t launch_blur(const float* x, float* out, int64_t n_img, int H, int W, const BlurTaps& T, int adjoint,
+                       hipStream_t st);
+hipError_t launch_gradient(const float* x, float* out, int64_t n_img, int H, int W, bool adjoint, hipStream_t st);
+hipError_t launch_dual_project(const float* y, float* out, int64_t n_img, int H, int W, float radius, int iso,
+                               hipStream_t st);
+hipError_t launch_eprox(int kind, const float* x, float* out, int64_t n, float p0, float p1, hipStream_t st);
+hipError_t launch_moments(const float* x, int C, int H, int W, double* s1, double* s2, hipStream_t st);
+hipError_t launch_energies(const float* x, int64_t n_img, const EnergyArgs& E, double* f_out, double* g_out,
+                           hipStream_t st);
+hipError_t launch_noise(float* out, int C, int H, int W, uint32_t key0, uint32_t key1, uint32_t iteration,
+                        uint32_t chain_offset, hipStream_t st);
+
+}  // namespace lmc

@@ -1,0 +1,293 @@
+// Stand-alone operator kernels of the plugin surface + diagnostics (moments, energies, noise dump).
+// These run outside the per-iteration hot loop (or once per kept sample) and are plain
+// coalesced global-memory kernels; the hot loop is lmc_step_*.hip.
+#include "lmc_device.h"
+#include "lmc_launch.h"
+
+namespace lmc {
+
+// ---- H x / H^T x  (Convolve2D.matvec / rmatvec) -------------------------------------------
+__global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                   int H, int W, BlurTaps T, int adjoint) {
+  const int gc = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int gr = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (gc >= W || gr >= H) return;
+  const size_t img = (size_t)H * W;
+  const float* xi = x + (size_t)blockIdx.z * img;
+  float acc = 0.f;
+  for (int a = 0; a < T.kh; ++a)
+    for (int b = 0; b < T.kw; ++b) {
+      const int r = adjoint ? gr + a - T.oy : gr - a + T.oy;
+      const int c = adjoint ? gc + b - T.ox : gc - b + T.ox;
+      if (r >= 0 && r < H && c >= 0 && c < W) acc = fmaf(T.h[a * T.kw + b], xi[(size_t)r * W + c], acc);
+    }
+  out[(size_t)blockIdx.z * img + (size_t)gr * W + gc] = acc;
+}
+
+hipError_t launch_blur(const float* x, float* out, int64_t n_img, int H, int W, const BlurTaps& T, int adjoint,
+                       hipStream_t st) {
+  const int64_t zmax = 65535;
+  for (int64_t z0 = 0; z0 < n_img; z0 += zmax) {
+    const int nz = (int)((n_img - z0) < zmax ? (n_img - z0) : zmax);
+    dim3 grid((W + 63) / 64, (H + 3) / 4, nz);
+    hipLaunchKernelGGL(blur_kernel, grid, dim3(256), 0, st, x + z0 * (size_t)H * W, out + z0 * (size_t)H * W, H, W, T,
+                       adjoint);
+  }
+  return hipGetLastError();
+}
+
+// ---- forward-difference gradient and its adjoint (pylops.Gradient, edge=False, forward) ----
+__global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__ x, float* __restrict__ out, int H,
+                                                       int W, int64_t n_img) {
+  const size_t img = (size_t)H * W;
+  const size_t total = img * n_img;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t im = i / img, p = i - im * img;
+    const int r = (int)(p / W), c = (int)(p - (size_t)r * W);
+    const float v = x[i];
+    out[im * 2 * img + p] = (r + 1 < H) ? x[i + W] - v : 0.f;
+    out[im * 2 * img + img + p] = (c + 1 < W) ? x[i + 1] - v : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void gradient_adjoint_kernel(const float* __restrict__ y, float* __restrict__ out,
+                                                               int H, int W, int64_t n_img) {
+  const size_t img = (size_t)H * W;
+  const size_t total = img * n_img;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t im = i / img, p = i - im * img;
+    const int r = (int)(p / W), c = (int)(p - (size_t)r * W);
+    const float* yr = y + im * 2 * img;
+    const float* yc = yr + img;
+    // A^T y = -div(y): -(yr[r]-yr[r-1]) - (yc[c]-yc[c-1]) with the last row/col of y ignored
+    float acc = 0.f;
+    if (r + 1 < H) acc -= yr[p];
+    if (r > 0) acc += yr[p - W];
+    if (c + 1 < W) acc -= yc[p];
+    if (c > 0) acc += yc[p - 1];
+    out[i] = acc;
+  }
+}
+
+static inline int grid_for(size_t total, int block) {
+  size_t g = (total + block - 1) / block;
+  return (int)(g < 8192 ? (g ? g : 1) : 8192);
+}
+
+hipError_t launch_gradient(const float* x, float* out, int64_t n_img, int H, int W, bool adjoint, hipStream_t st) {
+  const size_t total = (size_t)H * W * n_img;
+  if (adjoint)
+    hipLaunchKernelGGL(gradient_adjoint_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, x, out, H, W, n_img);
+  else
+    hipLaunchKernelGGL(gradient_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, x, out, H, W, n_img);
+  return hipGetLastError();
+}
+
+// ---- dual projections (L21.proxdual / L1.proxdual) -----------------------------------------
+__global__ __launch_bounds__(256) void dual_project_kernel(const float* __restrict__ y, float* __restrict__ out,
+                                                           size_t img, int64_t n_img, float radius, int iso) {
+  const size_t total = img * n_img;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t im = i / img, p = i - im * img;
+    const float a = y[im * 2 * img + p], b = y[im * 2 * img + img + p];
+    float oa, ob;
+    if (iso) {
+      const float nrm = sqrtf(fmaf(a, a, b * b));
+      const float sc = 1.f / fmaxf(1.f, nrm / radius);
+      oa = a * sc; ob = b * sc;
+    } else {
+      oa = fminf(fmaxf(a, -radius), radius);
+      ob = fminf(fmaxf(b, -radius), radius);
+    }
+    out[im * 2 * img + p] = oa;
+    out[im * 2 * img + img + p] = ob;
+  }
+}
+
+hipError_t launch_dual_project(const float* y, float* out, int64_t n_img, int H, int W, float radius, int iso,
+                               hipStream_t st) {
+  const size_t img = (size_t)H * W;
+  hipLaunchKernelGGL(dual_project_kernel, dim3(grid_for(img * n_img, 256)), dim3(256), 0, st, y, out, img, n_img,
+                     radius, iso);
+  return hipGetLastError();
+}
+
+// ---- closed-form elementwise proxes (prox.py:9-85) -----------------------------------------
+struct EproxParams { float p0, p1; };
+
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
+__device__ __forceinline__ float soft(float x, float t) { return copysignf(fmaxf(fabsf(x) - t, 0.f), x); }
+
+__device__ __forceinline__ float eprox(int kind, float x, EproxParams q) {
+  const float g = q.p0;
+  switch (kind) {
+    case LMC_EPROX_LAPLACE: return sgn(x) * fmaxf(fabsf(x) - g, 0.f);
+    case LMC_EPROX_UNCENTERED_LAPLACE: { const float d = x - q.p1; return q.p1 + sgn(d) * fmaxf(fabsf(d) - g, 0.f); }
+    case LMC_EPROX_GAUSSIAN: return x / (2.f * g + 1.f);
+    case LMC_EPROX_GEN_GAUSSIAN_4_3: {
+      const float xi = sqrtf(x * x + 256.f * g * g * g / 729.f);
+      return x + 4.f * g / (3.f * cbrtf(2.f)) * (cbrtf(xi - x) - cbrtf(xi + x));
+    }
+    case LMC_EPROX_GEN_GAUSSIAN_3_2:
+      return x + 9.f * g * g * sgn(x) * (1.f - sqrtf(1.f + 16.f * fabsf(x) / (9.f * g * g))) / 8.f;
+    case LMC_EPROX_GEN_GAUSSIAN_3: return sgn(x) * (sqrtf(1.f + 12.f * g * fabsf(x)) - 1.f) / (6.f * g);
+    case LMC_EPROX_GEN_GAUSSIAN_4: {
+      const float xi = sqrtf(x * x + 1.f / (27.f * g));
+      return cbrtf((xi + x) / (8.f * g)) - cbrtf((xi - x) / (8.f * g));
+    }
+    case LMC_EPROX_HUBER: {
+      const float t = q.p1;
+      return fabsf(x) <= g * (2.f * t + 1.f) / sqrtf(2.f * t) ? x / (2.f * t + 1.f) : x - g * sqrtf(2.f * t) * sgn(x);
+    }
+    case LMC_EPROX_SMOOTHED_LAPLACE: {
+      const float ax = fabsf(x), u = g * ax - g * g - 1.f;
+      return sgn(x) * (u + sqrtf(u * u + 4.f * g * ax)) / (2.f * g);
+    }
+    case LMC_EPROX_EXP: return x >= g ? x - g : 0.f;
+    case LMC_EPROX_GAMMA: { const float d = x - q.p0; return (d + sqrtf(d * d + 4.f * q.p1)) * 0.5f; }
+    case LMC_EPROX_CHI: return (x + sqrtf(x * x + 8.f * q.p0)) * 0.25f;
+    case LMC_EPROX_UNIFORM: return fminf(fmaxf(x, -q.p0), q.p0);
+    case LMC_EPROX_TRIANGULAR: {
+      const float o1 = q.p0, o2 = q.p1;
+      if (x < 1.f / o1) return (x + o1 + sqrtf((x - o1) * (x - o1) + 4.f)) * 0.5f;
+      if (x > 1.f / o2) return (x + o2 + sqrtf((x - o2) * (x - o2) + 4.f)) * 0.5f;
+      return 0.f;
+    }
+    case LMC_EPROX_LAPLACE_CONJ: {  // x - g * prox_laplace(x/g, 1/g)
+      const float z = x / g;
+      return x - g * (sgn(z) * fmaxf(fabsf(z) - 1.f / g, 0.f));
+    }
+  }
+  return x;
+}
+
+__global__ __launch_bounds__(256) void eprox_kernel(int kind, const float* __restrict__ x, float* __restrict__ out,
+                                                    size_t n, EproxParams q) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = eprox(kind, x[i], q);
+}
+
+hipError_t launch_eprox(int kind, const float* x, float* out, int64_t n, float p0, float p1, hipStream_t st) {
+  hipLaunchKernelGGL(eprox_kernel, dim3(grid_for((size_t)n, 256)), dim3(256), 0, st, kind, x, out, (size_t)n,
+                     EproxParams{p0, p1});
+  return hipGetLastError();
+}
+
+// ---- posterior moments: sum_c x, sum_c x^2 into fp64 accumulators --------------------------
+// grid.x covers pixels (one per thread, coalesced over chains), grid.y = chain segments.
+__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ x, int C, size_t img, int seg_len,
+                                                      double* __restrict__ s1, double* __restrict__ s2) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= img) return;
+  const int c0 = blockIdx.y * seg_len;
+  const int c1 = min(C, c0 + seg_len);
+  double a = 0.0, b = 0.0;
+  for (int c = c0; c < c1; ++c) {
+    const double v = (double)x[(size_t)c * img + p];
+    a += v;
+    b = fma(v, v, b);
+  }
+  unsafeAtomicAdd(&s1[p], a);
+  unsafeAtomicAdd(&s2[p], b);
+}
+
+hipError_t launch_moments(const float* x, int C, int H, int W, double* s1, double* s2, hipStream_t st) {
+  const size_t img = (size_t)H * W;
+  const int gx = (int)((img + 255) / 256);
+  int nseg = 1;
+  while ((size_t)gx * nseg < 2048 && nseg * 8 <= C) nseg *= 2;
+  const int seg_len = (C + nseg - 1) / nseg;
+  hipLaunchKernelGGL(moments_kernel, dim3(gx, nseg), dim3(256), 0, st, x, C, img, seg_len, s1, s2);
+  return hipGetLastError();
+}
+
+// ---- per-image energies f(x), g(x): wave-shuffle + LDS block reduction, one atomic per block -
+
+__global__ __launch_bounds__(256) void energy_kernel(const float* __restrict__ x, EnergyArgs E, double* __restrict__ f_out,
+                                                     double* __restrict__ g_out) {
+  __shared__ double scratch[4];
+  const int H = E.H, W = E.W;
+  const size_t img = (size_t)H * W;
+  const float* xi = x + (size_t)blockIdx.y * img;
+  double fa = 0.0, ga = 0.0;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < img; p += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(p / W), c = (int)(p - (size_t)r * W);
+    const float v = xi[p];
+    float res = 0.f;
+    if (E.data_kind == LMC_DATA_BLUR) {
+      float acc = 0.f;
+      for (int a = 0; a < E.blur.kh; ++a)
+        for (int b = 0; b < E.blur.kw; ++b) {
+          const int rr = r - a + E.blur.oy, cc = c - b + E.blur.ox;
+          if (rr >= 0 && rr < H && cc >= 0 && cc < W) acc = fmaf(E.blur.h[a * E.blur.kw + b], xi[(size_t)rr * W + cc], acc);
+        }
+      res = acc - E.y[p];
+    } else if (E.data_kind == LMC_DATA_IDENTITY) {
+      res = v - E.y[p];
+    } else if (E.data_kind == LMC_DATA_MASK) {
+      res = E.mask[p] * v - E.y[p];
+    }
+    fa += (double)res * (double)res;
+    if (E.prior_kind == LMC_PRIOR_TV_ISO) {
+      const float dx = (r + 1 < H) ? xi[p + W] - v : 0.f;
+      const float dy = (c + 1 < W) ? xi[p + 1] - v : 0.f;
+      ga += (double)sqrtf(fmaf(dx, dx, dy * dy));
+    } else if (E.prior_kind == LMC_PRIOR_L1) {
+      ga += (double)fabsf(v);
+    } else if (E.prior_kind == LMC_PRIOR_L2) {
+      ga += 0.5 * (double)v * (double)v;
+    }
+  }
+  const double ft = block_sum(fa, scratch);
+  const double gt = block_sum(ga, scratch);
+  if (threadIdx.x == 0) {
+    if (f_out) unsafeAtomicAdd(&f_out[blockIdx.y], 0.5 * (double)E.sigma_f * ft);
+    if (g_out) unsafeAtomicAdd(&g_out[blockIdx.y], (double)E.prior_sigma * gt);
+  }
+}
+
+hipError_t launch_energies(const float* x, int64_t n_img, const EnergyArgs& E, double* f_out, double* g_out,
+                           hipStream_t st) {
+  hipError_t e;
+  if (f_out && (e = hipMemsetAsync(f_out, 0, sizeof(double) * n_img, st)) != hipSuccess) return e;
+  if (g_out && (e = hipMemsetAsync(g_out, 0, sizeof(double) * n_img, st)) != hipSuccess) return e;
+  const size_t img = (size_t)E.H * E.W;
+  int gx = (int)((img + 255) / 256);
+  if (gx > 64) gx = 64;
+  const int64_t ymax = 65535;
+  for (int64_t z0 = 0; z0 < n_img; z0 += ymax) {
+    const int nz = (int)((n_img - z0) < ymax ? (n_img - z0) : ymax);
+    hipLaunchKernelGGL(energy_kernel, dim3(gx, nz), dim3(256), 0, st, x + z0 * img, E, f_out ? f_out + z0 : nullptr,
+                       g_out ? g_out + z0 : nullptr);
+  }
+  return hipGetLastError();
+}
+
+// ---- noise dump: the field xi[C][H][W] the step kernels draw at `iteration` -----------------
+__global__ __launch_bounds__(256) void noise_kernel(float* __restrict__ out, int C, int H, int W, uint32_t key0,
+                                                    uint32_t key1, uint32_t iteration, uint32_t chain_offset) {
+  const int nq = (H + 3) >> 2;
+  const size_t total = (size_t)C * nq * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % W);
+    const size_t t = i / W;
+    const int q = (int)(t % nq), c = (int)(t / nq);
+    float n[4];
+    quad_normals(key0, key1, iteration, chain_offset + (uint32_t)c, (uint32_t)q * (uint32_t)W + (uint32_t)col, n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * q + j;
+      if (r < H) out[((size_t)c * H + r) * W + col] = n[j];
+    }
+  }
+}
+
+hipError_t launch_noise(float* out, int C, int H, int W, uint32_t key0, uint32_t key1, uint32_t iteration,
+                        uint32_t chain_offset, hipStream_t st) {
+  const size_t total = (size_t)C * ((H + 3) / 4) * W;
+  hipLaunchKernelGGL(noise_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, out, C, H, W, key0, key1, iteration,
+                     chain_offset);
+  return hipGetLastError();
+}
+
+}  // namespace lmc

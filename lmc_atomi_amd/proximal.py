@@ -1,0 +1,281 @@
+"""Prox-operator plugin surface (pyproximal ``ProxOperator`` protocol as consumed by
+algs.py: ``obj(x)`` :461,578 ; ``obj.prox(x, tau)`` :440,569 ; ``obj.proxdual(x, tau)`` :436,448 ;
+``obj.grad(x)`` :569), computed by HIP kernels through the C ABI.
+
+Every class also exposes ``descriptor()``: the plain-data description the fused sampler
+kernels are configured from (``lmc_problem`` in include/lmc_atomi.h).  A device-side
+function-pointer plugin ABI is deliberately not offered (it would defeat fusion); new proxes
+are added as functors compiled into the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi, _dev
+from .operators import Convolve2D, Diagonal, Identity, LinearOperator
+
+
+def fgp_betas(niter, momentum="unlocbox"):
+    """Momentum table beta_k = (t_{k-1}-1)/t_k of the TV dual iteration.  'unlocbox' is the
+    sequence pyproximal.TV inherits from UNLocBoX [upstream]; 'fista' the textbook one."""
+    t, out = 1.0, []
+    for _ in range(int(niter)):
+        if momentum == "unlocbox":
+            tn = (1.0 + np.sqrt(4.0 * t * t)) / 2.0
+        elif momentum == "fista":
+            tn = (1.0 + np.sqrt(1.0 + 4.0 * t * t)) / 2.0
+        elif momentum == "none":
+            tn = 1.0
+        else:
+            raise ValueError(f"unknown momentum {momentum!r}")
+        out.append((t - 1.0) / tn)
+        t = tn
+    return np.asarray(out, dtype=np.float32)
+
+
+class ProxOperator:
+    """Base class; subclassing hook mirrors ``super().__init__(Op, hasgrad)`` (algs.py:132)."""
+
+    def __init__(self, Op=None, hasgrad=False):
+        self.Op = Op
+        self.hasgrad = hasgrad
+
+    def proxdual(self, x, tau):
+        """Moreau identity (prox.py:9-10): prox_{tau f*}(x) = x - tau prox_{f/tau}(x/tau)."""
+        return x - tau * self.prox(x / tau, 1.0 / tau)
+
+    def descriptor(self):
+        raise NotImplementedError(f"{type(self).__name__} has no device functor")
+
+
+class _Problem:
+    """Assembles an ``lmc_problem`` from a data-term descriptor and a prior descriptor and keeps
+    every buffer it points to alive."""
+
+    def __init__(self, dims, data=None, prior=None, dev=None):
+        self.dims = (int(dims[0]), int(dims[1]))
+        p = _capi.lmc_problem()
+        p.struct_size = C.sizeof(_capi.lmc_problem)
+        p.H, p.W = self.dims
+        self._keep = []
+        data = data or {"data_kind": _capi.DATA_NONE}
+        prior = prior or {"prior_kind": _capi.PRIOR_NONE}
+        p.data_kind = data["data_kind"]
+        p.sigma_f = float(data.get("sigma_f", 0.0))
+        if data.get("y") is not None:
+            y = _dev.to_dev(data["y"], dev).reshape(self.dims)
+            self._keep.append(y)
+            p.y_dev = y.data_ptr()
+        if data.get("mask") is not None:
+            m = _dev.to_dev(data["mask"], dev).reshape(self.dims)
+            self._keep.append(m)
+            p.mask_dev = m.data_ptr()
+        if p.data_kind == _capi.DATA_BLUR:
+            h = np.ascontiguousarray(data["h"], dtype=np.float32)
+            self._keep.append(h)
+            p.kh, p.kw = h.shape
+            p.oy, p.ox = data["offset"]
+            p.h_host = _dev.fptr(h)
+        p.prior_kind = prior["prior_kind"]
+        p.prior_sigma = float(prior.get("prior_sigma", 0.0))
+        if p.prior_kind == _capi.PRIOR_TV_ISO:
+            p.tv_niter = int(prior["tv_niter"])
+            p.tv_step = float(prior.get("tv_step", 0.125))
+            b = np.ascontiguousarray(prior["tv_betas"], dtype=np.float32)
+            if b.size != p.tv_niter:
+                raise ValueError("tv_betas must have tv_niter entries")
+            self._keep.append(b)
+            p.tv_betas_host = _dev.fptr(b)
+        self.c = p
+
+    def eval(self, x, a, t, b, pt):
+        """out = a*x - t*grad f(x) + b*prox_{pt*g}(x) for image-shaped / flat batches."""
+        n = self.dims[0] * self.dims[1]
+        xt = _dev.to_dev(x)
+        if xt.numel() % n:
+            raise ValueError(f"operand of shape {tuple(xt.shape)} is not a batch of {self.dims} images")
+        out = torch.empty_like(xt)
+        _capi.check(_dev.lib().lmc_fused_eval(C.byref(self.c), _dev.ptr(xt), _dev.ptr(out), xt.numel() // n,
+                                              a, t, b, pt, _dev.stream_ptr()))
+        return _dev.like_input(out, x)
+
+    def energies(self, x):
+        n = self.dims[0] * self.dims[1]
+        xt = _dev.to_dev(x)
+        n_img = xt.numel() // n
+        f = torch.empty(n_img, dtype=torch.float64, device=xt.device)
+        g = torch.empty(n_img, dtype=torch.float64, device=xt.device)
+        _capi.check(_dev.lib().lmc_energies(C.byref(self.c), _dev.ptr(xt), n_img, _dev.ptr(f), _dev.ptr(g),
+                                            _dev.stream_ptr()))
+        return f, g
+
+
+class L2(ProxOperator):
+    """``f(x) = sigma/2 ||Op x - b||^2`` -- drop-in for ``pyproximal.L2(Op=H, b=y, sigma=1/sigma**2,
+    niter=50, warm=True)`` (prox_lmc_deconv.py:101-103) and for the prior ``pyproximal.L2(sigma=lam)``.
+
+    ``Op`` may be a :class:`Convolve2D`, :class:`Diagonal`, :class:`Identity` or ``None``.
+    ``grad`` runs the fused blur-residual-adjoint kernel; value via the energy kernel.
+    The implicit step ``prox`` with an operator (row a8 of SURVEY section 8, used by ULPDA only) is
+    provided by :mod:`lmc_atomi_amd.algs` for ULPDA; for ``Op is None`` it is closed form.
+    """
+
+    def __init__(self, Op=None, b=None, sigma=1.0, niter=10, warm=True, dims=None):
+        super().__init__(Op, True)
+        self.b = b
+        self.sigma = float(sigma)
+        self.niter = niter
+        self.warm = warm
+        self.dims = dims if dims is not None else getattr(Op, "dims", None)
+        self._prob = None
+
+    # -- descriptors ---------------------------------------------------------------------
+    def descriptor(self):
+        """As the data term f of the sampler."""
+        if self.Op is None or isinstance(self.Op, Identity):
+            if self.b is None:
+                raise NotImplementedError("L2 without b as a data term: use it as the prior instead")
+            return {"data_kind": _capi.DATA_IDENTITY, "sigma_f": self.sigma, "y": self.b}
+        if isinstance(self.Op, Convolve2D):
+            return {"data_kind": _capi.DATA_BLUR, "sigma_f": self.sigma, "y": self.b, "h": self.Op.h,
+                    "offset": self.Op.offset}
+        if isinstance(self.Op, Diagonal):
+            return {"data_kind": _capi.DATA_MASK, "sigma_f": self.sigma, "y": self.b, "mask": self.Op.d}
+        raise NotImplementedError(f"no device functor for L2 with Op of type {type(self.Op).__name__}")
+
+    def prior_descriptor(self):
+        """As the prior g = sigma/2 ||x||^2 (closed-form prox)."""
+        if self.Op is not None or self.b is not None:
+            raise NotImplementedError("only L2(sigma=...) without Op/b can act as the prior")
+        return {"prior_kind": _capi.PRIOR_L2, "prior_sigma": self.sigma}
+
+    def _problem(self):
+        if self._prob is None:
+            if self.dims is None:
+                raise ValueError("L2 needs `dims` (image shape) when Op does not carry it")
+            self._prob = _Problem(self.dims, data=self.descriptor())
+        return self._prob
+
+    # -- protocol ------------------------------------------------------------------------
+    def __call__(self, x):
+        if self.Op is None and self.b is None:       # pure quadratic prior sigma/2 ||x||^2
+            xt = _dev.to_dev(x).reshape(1, -1)
+            _, g = _Problem((1, xt.shape[1]), prior=self.prior_descriptor()).energies(xt)
+            return float(g[0])
+        f, _ = self._problem().energies(x)
+        return float(f[0]) if f.numel() == 1 else (f if isinstance(x, torch.Tensor) else f.cpu().numpy())
+
+    def grad(self, x):
+        return self._problem().eval(x, 0.0, -1.0, 0.0, 0.0)
+
+    def prox(self, x, tau):
+        if self.Op is None:
+            if self.b is None:
+                return x / (1.0 + tau * self.sigma)
+            return (x + tau * self.sigma * self.b) / (1.0 + tau * self.sigma)
+        raise NotImplementedError("implicit L2 step with an operator: handled by UnadjustedLangevinPrimalDual")
+
+
+class L1(ProxOperator):
+    """``sigma ||x||_1`` -- drop-in for ``pyproximal.L1(sigma=tau)`` (prox_lmc_deconv.py:119)."""
+
+    def __init__(self, sigma=1.0, dims=None):
+        super().__init__(None, False)
+        self.sigma = float(sigma)
+        self.dims = dims
+
+    def prior_descriptor(self):
+        return {"prior_kind": _capi.PRIOR_L1, "prior_sigma": self.sigma}
+
+    def __call__(self, x):
+        xt = _dev.to_dev(x).reshape(1, -1)
+        p = _Problem((1, xt.shape[1]), prior=self.prior_descriptor())
+        _, g = p.energies(xt)
+        return float(g[0])
+
+    def prox(self, x, tau):
+        xt = _dev.to_dev(x)
+        out = torch.empty_like(xt)
+        par = np.asarray([self.sigma * float(tau)], dtype=np.float32)
+        _capi.check(_dev.lib().lmc_prox_elementwise(_capi.EPROX_LAPLACE, _dev.ptr(xt), _dev.ptr(out), xt.numel(),
+                                                    _dev.fptr(par), 1, _dev.stream_ptr()))
+        return _dev.like_input(out, x)
+
+    def proxdual(self, x, tau):
+        """Clip to [-sigma, sigma] (projection onto the dual ball)."""
+        xt = _dev.to_dev(x)
+        out = torch.empty_like(xt)
+        par = np.asarray([self.sigma], dtype=np.float32)
+        _capi.check(_dev.lib().lmc_prox_elementwise(_capi.EPROX_UNIFORM, _dev.ptr(xt), _dev.ptr(out), xt.numel(),
+                                                    _dev.fptr(par), 1, _dev.stream_ptr()))
+        return _dev.like_input(out, x)
+
+
+class L21(ProxOperator):
+    """``sigma * sum_pixels ||(v_row, v_col)||_2`` on stacked fields of length 2n -- drop-in for
+    ``pyproximal.L21(ndim=2, sigma=tau)`` (prox_lmc_deconv.py:116)."""
+
+    def __init__(self, ndim=2, sigma=1.0):
+        if ndim != 2:
+            raise NotImplementedError("ndim=2 only (the reference's configuration)")
+        super().__init__(None, False)
+        self.ndim = ndim
+        self.sigma = float(sigma)
+
+    def __call__(self, x):
+        xt = _dev.to_dev(x).reshape(2, -1)
+        return self.sigma * float(torch.sqrt((xt.double() ** 2).sum(0)).sum())
+
+    def proxdual(self, x, tau):
+        xt = _dev.to_dev(x)
+        n2 = xt.shape[-1]
+        if n2 % 2:
+            raise ValueError("stacked field must have even length")
+        out = torch.empty_like(xt)
+        _capi.check(_dev.lib().lmc_dual_project(_dev.ptr(xt), _dev.ptr(out), xt.numel() // n2, 1, n2 // 2,
+                                                self.sigma, 1, _dev.stream_ptr()))
+        return _dev.like_input(out, x)
+
+    def prox(self, x, tau):
+        """Moreau identity with the dual projection: prox_{tau g}(x) = x - proj_{tau*sigma}(x)."""
+        xt = _dev.to_dev(x)
+        n2 = xt.shape[-1]
+        out = torch.empty_like(xt)
+        _capi.check(_dev.lib().lmc_dual_project(_dev.ptr(xt), _dev.ptr(out), xt.numel() // n2, 1, n2 // 2,
+                                                self.sigma * float(tau), 1, _dev.stream_ptr()))
+        return _dev.like_input(xt - out, x)
+
+
+class TV(ProxOperator):
+    """``sigma * TV_iso(x)`` -- drop-in for ``pyproximal.TV(dims=img.shape, sigma=tau, niter=niter_tv)``
+    (prox_lmc_deconv.py:122).  ``prox`` runs ``niter`` fast-gradient-projection dual iterations fully
+    on chip (fixed count; the reference's data-dependent ``rtol`` early exit is not taken: a batched
+    launch does identical work for every chain)."""
+
+    def __init__(self, dims, sigma=1.0, niter=10, rtol=0.0, step=0.125, momentum="unlocbox"):
+        super().__init__(None, False)
+        self.dims = (int(dims[0]), int(dims[1]))
+        self.sigma = float(sigma)
+        self.niter = int(niter)
+        self.step = float(step)
+        self.momentum = momentum
+        self._prob = None
+
+    def prior_descriptor(self):
+        return {"prior_kind": _capi.PRIOR_TV_ISO, "prior_sigma": self.sigma, "tv_niter": self.niter,
+                "tv_step": self.step, "tv_betas": fgp_betas(self.niter, self.momentum)}
+
+    def _problem(self):
+        if self._prob is None:
+            self._prob = _Problem(self.dims, prior=self.prior_descriptor())
+        return self._prob
+
+    def __call__(self, x):
+        _, g = self._problem().energies(x)
+        return float(g[0]) if g.numel() == 1 else (g if isinstance(x, torch.Tensor) else g.cpu().numpy())
+
+    def prox(self, x, tau):
+        return self._problem().eval(x, 0.0, 0.0, 1.0, float(tau))
