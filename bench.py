@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- LMC chain-iterations/s on MI355X (BASELINE.json metric), with the HBM roofline of the
+fused step kernel and the CPU oracle timed beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one MYULA iteration (algs.py:569) of every chain resident on the GPU.  Workload at
+N = 1: BASELINE.json configs[2] -- 512x512 deblurring (5x5 uniform box blur as prox_lmc_deconv.py:55-58,
+Gaussian noise sigma = 0.75) + isotropic TV prox (niter_tv = 10 dual iterations), 1024 chains.  For N > 1
+every rank runs 1024 chains of its own (weak scaling, configs[3]: 8192 chains on 8 GPUs), chains keyed by
+global id, and the only collective is one RCCL all-reduce of the posterior moment images at the end of the
+timed region.  Inputs are synthetic and resident in HBM before the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+BYTES_PER_PIXEL_STEP = 8       # algorithmic: one fp32 read of x_k + one fp32 write of x_{k+1}
+
+
+def synth_problem(H, W, sigma, seed=0):
+    """Piecewise-constant + ramp ground truth in [0,255] from default_rng(1234); y = H u + N(0, sigma^2)
+    with noise from default_rng(seed) (mirrors prox_lmc_deconv.py:53-59).  Host-side setup, not timed."""
+    rng = np.random.default_rng(1234)
+    u = np.zeros((H, W))
+    for _ in range(12):
+        i0, j0 = rng.integers(0, H - 8), rng.integers(0, W - 8)
+        i1, j1 = rng.integers(i0 + 4, H + 1), rng.integers(j0 + 4, W + 1)
+        u[i0:i1, j0:j1] = rng.uniform(20, 235)
+    u += np.linspace(0, 20, W)[None, :]
+    u = np.clip(u, 0, 255)
+    h = np.ones((5, 5)) / 25.0
+    # blur with scipy (setup only): zero-padded 'same' convolution, centred 5x5
+    import scipy.signal
+    y = scipy.signal.convolve2d(u, h, mode="same") + np.random.default_rng(seed).normal(0, sigma, (H, W))
+    return u, h, y
+
+
+def cpu_baseline(H, W, h, y, sigma, tau_reg, niter_tv, chains=4, iters=20):
+    """The oracle (numpy restatement of the reference loop, float64, PCG64 noise, 1 thread) on a bounded
+    sample of the same workload.  Checker / baseline only -- never on the product path."""
+    from oracle import lmc_oracle as O
+    gamma, tau = sigma ** 2, 0.2 * sigma ** 2
+    prior = {"kind": "tv", "sigma": tau_reg, "niter": niter_tv, "t": gamma}
+    rng = np.random.default_rng(0)
+    x = np.zeros((chains, H, W))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        x = O.myula_step(x, y, h, (2, 2), 1 / sigma ** 2, tau, gamma, prior, rng.standard_normal(x.shape))
+    dt = time.perf_counter() - t0
+    return {"value": chains * iters / dt, "unit": "chain-it/s", "cores": 1, "kind": "port",
+            "sample": f"{chains} chains x {iters} iterations of the same {H}x{W} MYULA-TV(K={niter_tv}) workload, "
+                      f"oracle/lmc_oracle.py float64 numpy, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
+    ap.add_argument("--tv-iters", type=int, default=10)
+    ap.add_argument("--prior", default="tv", choices=["tv", "l2", "l1"])
+    ap.add_argument("--thin", type=int, default=1, help="accumulate posterior moments every thin-th iteration")
+    ap.add_argument("--no-moments", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-chains", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import lmc_atomi_amd as la
+
+    H = W = args.size
+    C = args.chains
+    sigma, tau_reg = 0.75, 0.3                       # prox_lmc_deconv.py:40 defaults
+    gamma, tau = sigma ** 2, 0.2 * sigma ** 2        # prox_lmc_deconv.py:92-94
+    u, h, y = synth_problem(H, W, sigma)
+    pf = la.L2(Op=la.Convolve2D((H, W), h, offset=(2, 2)), b=y, sigma=1 / sigma ** 2)
+    pg = {"tv": la.TV((H, W), sigma=tau_reg, niter=args.tv_iters), "l2": la.L2(sigma=0.05),
+          "l1": la.L1(sigma=tau_reg)}[args.prior]
+    smp = la.MYULASampler(pf, pg, (H, W), n_chains=C, tau=tau, gamma=gamma, seed=0, chain_offset=rank * C,
+                          moments=not args.no_moments, burn_in=0, thin=args.thin)
+    smp.set_state(np.zeros((H, W), dtype=np.float32))        # x0 = 0 (prox_lmc_deconv.py:135)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    smp.step(args.warmup)
+    if not args.no_moments:
+        smp.reset_moments()
+    smp.enable_timing(True)
+    sync_all()
+    t0 = time.perf_counter()
+    smp.step(args.steps)
+    if world > 1 and not args.no_moments:
+        s1, s2, cnt = smp.moments()
+        packed = torch.stack([s1, s2])
+        dist.all_reduce(packed)                              # RCCL over xGMI: posterior mean/var accumulators
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    kern_ms, launches = smp.last_step_timing()
+
+    if rank == 0:
+        value = C * world * args.steps / elapsed
+        per_launch_ms = kern_ms / launches
+        achieved = BYTES_PER_PIXEL_STEP * H * W * C / (per_launch_ms * 1e-3) / 1e9
+        prior_desc = (f"isotropic TV prox K={args.tv_iters} (tau_reg={tau_reg})" if args.prior == "tv"
+                      else f"{args.prior} prior")
+        out = {
+            "metric": "lmc_chain_iterations_per_s",
+            "value": value,
+            "unit": "chain-it/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{H}x{W} MYULA deblur (5x5 uniform box blur, sigma={sigma}) + {prior_desc}, "
+                            f"{C} chains/GPU x {world} GPU, Philox noise, x0=0, "
+                            + ("no moments" if args.no_moments else f"posterior moments every {args.thin} it"),
+                "image": [H, W], "chains_per_gpu": C, "chains_total": C * world, "tv_iters": args.tv_iters,
+                "sampler": "MYULA (algs.py:477-587)", "parallelism": f"chains sharded x{world}",
+                "iterations_per_s": args.steps / elapsed,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": smp.kernel_name,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "launch_ms": per_launch_ms,
+                "launches": launches,
+                "algorithmic_bytes_per_launch": BYTES_PER_PIXEL_STEP * H * W * C,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(H, W, h, y, sigma, tau_reg, args.tv_iters, args.cpu_chains, args.cpu_iters)
+        print(json.dumps(out))
+    smp.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -178,8 +178,11 @@ int lmc_sampler_reset_moments(lmc_sampler* s, void* stream);
 int lmc_sampler_energies(lmc_sampler* s, double* f_out_dev, double* g_out_dev, void* stream);
 /* the noise field xi[n_chains][H][W] the sampler draws at `iteration` (parity rung R3) */
 int lmc_sampler_noise(lmc_sampler* s, int64_t iteration, float* out_dev, void* stream);
-/* HIP-event timing of the step kernels launched by the LAST lmc_sampler_step call on its stream:
- * total milliseconds and number of step-kernel launches (bench.py's roofline leg). */
+/* HIP-event timing of the step kernels: when enabled, lmc_sampler_step brackets EACH step-kernel
+ * launch with its own event pair on the launch stream (interleaved moment reductions stay outside).
+ * last_step_timing returns the summed kernel milliseconds and the number of launches of the LAST
+ * lmc_sampler_step call (bench.py's roofline leg); it synchronises on the last event. */
+int lmc_sampler_enable_timing(lmc_sampler* s, int32_t on);
 int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_launches);
 /* name of the step kernel variant selected for this configuration (for profiles/) */
 const char* lmc_sampler_kernel_name(const lmc_sampler* s);

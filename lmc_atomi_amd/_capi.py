@@ -89,6 +89,7 @@ _SIGNATURES = {
     "lmc_sampler_reset_moments": (C.c_int, [_P, _P]),
     "lmc_sampler_energies": (C.c_int, [_P, _P, _P, _P]),
     "lmc_sampler_noise": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "lmc_sampler_enable_timing": (C.c_int, [_P, C.c_int32]),
     "lmc_sampler_last_step_timing": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "lmc_sampler_kernel_name": (C.c_char_p, [_P]),
 }

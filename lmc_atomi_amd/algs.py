@@ -131,7 +131,12 @@ class MYULASampler:
         if nt is not None:
             torch.cuda.current_stream().synchronize()
 
+    def enable_timing(self, on=True):
+        """Bracket every step-kernel launch with a HIP event pair on the launch stream."""
+        _capi.check(_dev.lib().lmc_sampler_enable_timing(self._h, 1 if on else 0))
+
     def last_step_timing(self):
+        """(summed step-kernel milliseconds, launches) of the last :meth:`step` call."""
         ms, n = C.c_float(), C.c_int32()
         _capi.check(_dev.lib().lmc_sampler_last_step_timing(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value

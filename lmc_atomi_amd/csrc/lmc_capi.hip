@@ -153,7 +153,8 @@ struct lmc_sampler {
   double* s1 = nullptr;
   double* s2 = nullptr;
   lmc::StepArgs base{};
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> ev;   // pairs (begin, end) around each step-kernel launch of the last step() call
+  bool timing = false;
   bool timed = false;
   int last_launches = 0;
   std::string kernel_name;
@@ -302,8 +303,6 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
     if (e == hipSuccess) e = hipMemset(s->s1, 0, mb);
     if (e == hipSuccess) e = hipMemset(s->s2, 0, mb);
   }
-  if (e == hipSuccess) e = hipEventCreate(&s->ev0);
-  if (e == hipSuccess) e = hipEventCreate(&s->ev1);
   if (e != hipSuccess) {
     rc = fail(e == hipErrorOutOfMemory ? LMC_E_NOMEM : LMC_E_HIP, "sampler allocation failed: %s", hipGetErrorString(e));
     lmc_sampler_destroy(s);
@@ -320,8 +319,7 @@ void lmc_sampler_destroy(lmc_sampler* s) {
   if (s->x[1]) (void)hipFree(s->x[1]);
   if (s->s1) (void)hipFree(s->s1);
   if (s->s2) (void)hipFree(s->s2);
-  if (s->ev0) (void)hipEventDestroy(s->ev0);
-  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
   delete s;
 }
 
@@ -352,18 +350,24 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
   s->timed = false;
   s->last_launches = 0;
   if (n_iters == 0) return LMC_OK;
-  HIP_TRY(hipEventRecord(s->ev0, st));
-  // The event pair brackets ONLY step kernels when moments are off; with moments on the
-  // interleaved reduction launches are inside the bracket too (reported as such by the caller).
+  if (s->timing) {  // one event pair per step-kernel launch: moment reductions stay outside the brackets
+    while ((int)s->ev.size() < 2 * n_iters) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      s->ev.push_back(e);
+    }
+  }
   for (int k = 0; k < n_iters; ++k) {
     lmc::StepArgs A = s->base;
     A.x_in = s->x[s->cur];
     A.x_out = s->x[s->cur ^ 1];
     A.iteration = (uint32_t)s->iteration;
     A.noise = noise_dev ? noise_dev + (size_t)k * per_iter : nullptr;
+    if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * k], st));
     hipError_t e = lmc::launch_step_tile(A, st);
     if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no tile plan fits LDS for this halo");
     HIP_TRY(e);
+    if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * k + 1], st));
     s->cur ^= 1;
     if (s->moments && s->iteration >= s->burn_in && (s->iteration - s->burn_in) % s->thin == 0) {
       HIP_TRY(lmc::launch_moments(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st));
@@ -372,8 +376,14 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     ++s->iteration;
     ++s->last_launches;
   }
-  HIP_TRY(hipEventRecord(s->ev1, st));
-  s->timed = true;
+  s->timed = s->timing;
+  return LMC_OK;
+}
+
+int lmc_sampler_enable_timing(lmc_sampler* s, int32_t on) {
+  if (!s) return fail(LMC_E_INVALID, "NULL sampler");
+  s->timing = on != 0;
+  s->timed = false;
   return LMC_OK;
 }
 
@@ -422,10 +432,15 @@ int lmc_sampler_noise(lmc_sampler* s, int64_t iteration, float* out_dev, void* s
 
 int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_launches) {
   if (!s) return fail(LMC_E_INVALID, "NULL sampler");
-  if (!s->timed) return fail(LMC_E_STATE, "no timed lmc_sampler_step call to report");
-  HIP_TRY(hipEventSynchronize(s->ev1));
+  if (!s->timed || s->last_launches < 1)
+    return fail(LMC_E_STATE, "no timed lmc_sampler_step call to report (lmc_sampler_enable_timing first)");
+  HIP_TRY(hipEventSynchronize(s->ev[2 * s->last_launches - 1]));
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+  for (int k = 0; k < s->last_launches; ++k) {
+    float d = 0.f;
+    HIP_TRY(hipEventElapsedTime(&d, s->ev[2 * k], s->ev[2 * k + 1]));
+    ms += d;
+  }
   if (total_ms) *total_ms = ms;
   if (n_launches) *n_launches = s->last_launches;
   return LMC_OK;

@@ -91,7 +91,12 @@ def test_l2_grad_and_value(la, k, shape):
     off = (k // 2, k // 2)
     l2 = la.L2(Op=la.Convolve2D(shape, h, offset=off), b=y.ravel(), sigma=1 / 0.75 ** 2)
     l2o = O.L2(Op=O.Convolve2D(shape, h, offset=off), b=y.ravel(), sigma=1 / 0.75 ** 2)
-    assert rel(l2.grad(x.ravel()), l2o.grad(x.ravel())) < STEP_TOL
+    # grad = sigma_f H^T(Hx - y) cancels Hx ~ 200 against y ~ 200: the fp32 error is relative to the
+    # operands before the cancellation (it enters the MYULA update multiplied by tau, i.e. at 1e-7 of x)
+    got, ref = l2.grad(x.ravel()), l2o.grad(x.ravel())
+    scale = (1 / 0.75 ** 2) * (np.linalg.norm(l2o.Op.rmatvec(l2o.Op.matvec(x.ravel()))) + np.linalg.norm(l2o.Op.rmatvec(y.ravel())))
+    assert np.linalg.norm(got - ref) < 2e-7 * scale
+    assert rel(got, ref) < 1e-4
     assert abs(l2(x.ravel()) - l2o(x.ravel())) < 1e-5 * abs(l2o(x.ravel()))
 
 
