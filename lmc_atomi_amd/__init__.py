@@ -6,11 +6,12 @@ from . import _capi
 from ._capi import LMCError
 from .operators import Convolve2D, Diagonal, Gradient, Identity, LinearOperator
 from .proximal import L1, L2, L21, TV, ProxOperator, fgp_betas
-from .algs import (MYULAResult, MYULASampler, MoreauYosidaUnadjustedLangevin, mean_var_from_moments)
+from .algs import (MYULAResult, MYULASampler, MoreauYosidaUnadjustedLangevin, mean_var_from_moments,
+                   set_step_variant)
 
 __all__ = [
     "LMCError", "Convolve2D", "Diagonal", "Gradient", "Identity", "LinearOperator",
     "L1", "L2", "L21", "TV", "ProxOperator", "fgp_betas",
-    "MYULASampler", "MYULAResult", "MoreauYosidaUnadjustedLangevin", "mean_var_from_moments",
+    "MYULASampler", "MYULAResult", "MoreauYosidaUnadjustedLangevin", "mean_var_from_moments", "set_step_variant",
 ]
 __version__ = "0.1.0"

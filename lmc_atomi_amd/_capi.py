@@ -92,6 +92,7 @@ _SIGNATURES = {
     "lmc_sampler_enable_timing": (C.c_int, [_P, C.c_int32]),
     "lmc_sampler_last_step_timing": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "lmc_sampler_kernel_name": (C.c_char_p, [_P]),
+    "lmc_set_step_variant": (C.c_int, [C.c_int32]),
 }
 
 _lib = None

@@ -136,6 +136,22 @@ int make_step_args(const Problem& q, float a, float t, float b, float pt, float 
   return LMC_OK;
 }
 
+int g_variant = 0;  // 0 auto, 1 tile, 2 stream
+
+// Picks the step-kernel variant: the streaming register pipeline when it covers the configuration
+// (W <= 512, separable blur, supported K), else the LDS-tiled kernel.
+hipError_t launch_step(const lmc::StepArgs& A, hipStream_t st, const char** name) {
+  const bool can_stream = lmc::stream_supported(A);
+  const bool use_stream = g_variant == 2 ? true : (g_variant == 1 ? false : can_stream);
+  if (use_stream) {
+    if (!can_stream) return hipErrorInvalidConfiguration;
+    if (name) *name = "myula_step_stream_kernel";
+    return lmc::launch_step_stream(A, st);
+  }
+  if (name) *name = "myula_step_tile_kernel";
+  return lmc::launch_step_tile(A, st);
+}
+
 }  // namespace
 
 struct lmc_sampler {
@@ -217,8 +233,8 @@ int lmc_fused_eval(const lmc_problem* prob, const float* x_dev, float* out_dev, 
   A.C = (int)n_img;
   A.x_in = x_dev;
   A.x_out = out_dev;
-  hipError_t e = lmc::launch_step_tile(A, S(stream));
-  if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no tile plan fits LDS for this halo");
+  hipError_t e = launch_step(A, S(stream), nullptr);
+  if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no step-kernel variant covers this configuration");
   HIP_TRY(e);
   return LMC_OK;
 }
@@ -308,7 +324,7 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
     lmc_sampler_destroy(s);
     return rc;
   }
-  s->kernel_name = s->prob.prior_kind == LMC_PRIOR_TV_ISO ? "myula_step_tile_kernel<NP,true>" : "myula_step_tile_kernel<NP,false>";
+  s->kernel_name = "(no step launched yet)";
   *out = s;
   return LMC_OK;
 }
@@ -364,9 +380,11 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     A.iteration = (uint32_t)s->iteration;
     A.noise = noise_dev ? noise_dev + (size_t)k * per_iter : nullptr;
     if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * k], st));
-    hipError_t e = lmc::launch_step_tile(A, st);
-    if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no tile plan fits LDS for this halo");
+    const char* kname = nullptr;
+    hipError_t e = launch_step(A, st, &kname);
+    if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no step-kernel variant covers this configuration");
     HIP_TRY(e);
+    if (kname) s->kernel_name = kname;
     if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * k + 1], st));
     s->cur ^= 1;
     if (s->moments && s->iteration >= s->burn_in && (s->iteration - s->burn_in) % s->thin == 0) {
@@ -447,5 +465,12 @@ int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_lau
 }
 
 const char* lmc_sampler_kernel_name(const lmc_sampler* s) { return s ? s->kernel_name.c_str() : ""; }
+
+int lmc_set_step_variant(int32_t variant) {
+  if (variant < 0 || variant > 2) return fail(LMC_E_INVALID, "variant must be 0 (auto), 1 (tile) or 2 (stream)");
+  const int prev = g_variant;
+  g_variant = variant;
+  return prev;
+}
 
 }  // extern "C"

@@ -29,3 +29,9 @@ hipError_t launch_noise(float* out, int C, int H, int W, uint32_t key0, uint32_t
                         uint32_t chain_offset, hipStream_t st);
 
 }  // namespace lmc
+
+namespace lmc {
+// streaming register-pipeline variant (lmc_step_stream.hip)
+bool stream_supported(const StepArgs& a);
+hipError_t launch_step_stream(StepArgs a, hipStream_t st);
+}  // namespace lmc

@@ -30,6 +30,15 @@ def la():
     return la
 
 
+@pytest.fixture(autouse=True, params=["tile", "auto"])
+def variant(request, la):
+    """Every test runs twice: with the LDS-tiled step kernel forced, and with the default choice
+    (the streaming register-pipeline kernel wherever it covers the configuration)."""
+    prev = la.set_step_variant(request.param)
+    yield request.param
+    la.set_step_variant(prev)
+
+
 def synth(ny, nx, seed=0, k=5, sigma=0.75):
     rng = np.random.default_rng(seed)
     img = np.zeros((ny, nx))
@@ -191,6 +200,27 @@ def test_multi_step_call_equals_single_steps(la):
     for _ in range(6):
         b.step(1)
     np.testing.assert_array_equal(a.get_state().cpu().numpy(), b.get_state().cpu().numpy())
+
+
+def test_stream_and_tile_variants_agree(la):
+    """Same inputs through both step kernels (different on-chip schedules of the same arithmetic)."""
+    rng = np.random.default_rng(2)
+    for shape, k, niter in [((64, 64), 5, 10), ((100, 200), 7, 4), ((37, 130), 6, 3), ((512, 512), 5, 10),
+                            ((40, 256), 5, 16), ((9, 33), 3, 1)]:
+        img, h, y = synth(*shape, seed=1, k=k)
+        pf = la.L2(Op=la.Convolve2D(shape, h, offset=(k // 2, k // 2)), b=y, sigma=1 / 0.75 ** 2)
+        pg = la.TV(shape, sigma=0.3, niter=niter)
+        x0 = img[None] + rng.normal(0, 10, (2,) + shape)
+        outs = {}
+        for v in ("tile", "stream"):
+            la.set_step_variant(v)
+            smp = la.MYULASampler(pf, pg, shape, n_chains=2, tau=0.1125, gamma=0.5625, seed=5)
+            smp.set_state(x0)
+            smp.step(3)
+            outs[v] = smp.get_state().cpu().numpy()
+            assert v in smp.kernel_name
+            smp.close()
+        assert rel(outs["stream"], outs["tile"]) < 2e-6, (shape, rel(outs["stream"], outs["tile"]))
 
 
 # ------------------------------------------------------------------ RNG rung (R3)
