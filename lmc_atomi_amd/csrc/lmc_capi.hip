@@ -136,6 +136,14 @@ int make_step_args(const Problem& q, float a, float t, float b, float pt, float 
   return LMC_OK;
 }
 
+// Pointers that the configuration does not use are pointed at the input state (always valid for the
+// index ranges the kernels form) so that no kernel ever holds a null pointer it could dereference.
+void sanitize_pointers(lmc::StepArgs& A) {
+  if (!A.y) A.y = A.x_in;
+  if (!A.mask) A.mask = A.x_in;
+  if (!A.noise) A.noise = A.x_in;
+}
+
 int g_variant = 0;  // 0 auto, 1 tile, 2 stream
 
 // Picks the step-kernel variant: the streaming register pipeline when it covers the configuration
@@ -233,6 +241,7 @@ int lmc_fused_eval(const lmc_problem* prob, const float* x_dev, float* out_dev, 
   A.C = (int)n_img;
   A.x_in = x_dev;
   A.x_out = out_dev;
+  sanitize_pointers(A);
   hipError_t e = launch_step(A, S(stream), nullptr);
   if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no step-kernel variant covers this configuration");
   HIP_TRY(e);
@@ -379,6 +388,7 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     A.x_out = s->x[s->cur ^ 1];
     A.iteration = (uint32_t)s->iteration;
     A.noise = noise_dev ? noise_dev + (size_t)k * per_iter : nullptr;
+    sanitize_pointers(A);
     if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * k], st));
     const char* kname = nullptr;
     hipError_t e = launch_step(A, st, &kname);

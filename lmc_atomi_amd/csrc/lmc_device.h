@@ -29,13 +29,15 @@ __device__ __forceinline__ float u01(uint32_t u) {
 }
 
 // Two N(0,1) per uint32 pair: r = sqrt(-2 ln u_a); (r sin 2*pi*u_b, r cos 2*pi*u_b).
+// Hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in
+// revolutions, so 2*pi*u_b needs no multiply and no range reduction: u_b is in (0,1]).
+// Absolute error of a deviate vs exact arithmetic: < 2e-5 (tests/test_gpu_parity.py), i.e. < 1e-5 of
+// the noise scale sqrt(2 tau) -- statistically irrelevant, and identical in every kernel that draws noise.
 __device__ __forceinline__ void box_muller(uint32_t ua, uint32_t ub, float& n0, float& n1) {
   const float u1 = u01(ua), u2 = u01(ub);
-  const float r = sqrtf(-2.0f * logf(u1));
-  float sn, cs;
-  sincospif(2.0f * u2, &sn, &cs);
-  n0 = r * sn;
-  n1 = r * cs;
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln2 log2(u1)
+  n0 = r * __builtin_amdgcn_sinf(u2);
+  n1 = r * __builtin_amdgcn_cosf(u2);
 }
 
 // The 4 normals of quad (row>>2, col) of `chain` at `iteration`: rows 4q+0..3 of column col.

@@ -206,7 +206,7 @@ def test_stream_and_tile_variants_agree(la):
     """Same inputs through both step kernels (different on-chip schedules of the same arithmetic)."""
     rng = np.random.default_rng(2)
     for shape, k, niter in [((64, 64), 5, 10), ((100, 200), 7, 4), ((37, 130), 6, 3), ((512, 512), 5, 10),
-                            ((40, 256), 5, 16), ((9, 33), 3, 1)]:
+                            ((40, 256), 5, 12), ((9, 33), 3, 1)]:
         img, h, y = synth(*shape, seed=1, k=k)
         pf = la.L2(Op=la.Convolve2D(shape, h, offset=(k // 2, k // 2)), b=y, sigma=1 / 0.75 ** 2)
         pg = la.TV(shape, sigma=0.3, niter=niter)
@@ -221,6 +221,18 @@ def test_stream_and_tile_variants_agree(la):
             assert v in smp.kernel_name
             smp.close()
         assert rel(outs["stream"], outs["tile"]) < 2e-6, (shape, rel(outs["stream"], outs["tile"]))
+    # a configuration the streaming kernel does not cover (K = 16): forcing it is an error, the default falls back
+    shape = (40, 96)
+    img, h, y = synth(*shape, seed=1)
+    pf = la.L2(Op=la.Convolve2D(shape, h), b=y, sigma=1 / 0.75 ** 2)
+    pg = la.TV(shape, sigma=0.3, niter=16)
+    la.set_step_variant("stream")
+    smp = la.MYULASampler(pf, pg, shape, n_chains=1, tau=0.1125, gamma=0.5625)
+    with pytest.raises(la.LMCError, match="no step-kernel variant"):
+        smp.step(1)
+    la.set_step_variant("auto")
+    smp.step(1)
+    assert "tile" in smp.kernel_name
 
 
 # ------------------------------------------------------------------ RNG rung (R3)
@@ -231,7 +243,7 @@ def test_philox_noise_field_matches_oracle(la):
     for it in (0, 3, 1000):
         got = smp.noise_field(it).cpu().numpy()
         ref = O.philox_normals(0x1234567890ABCDEF, it, np.arange(7, 12), *shape)
-        assert np.abs(got - ref).max() < 4e-6, np.abs(got - ref).max()
+        assert np.abs(got - ref).max() < 2e-5, np.abs(got - ref).max()   # hardware log2/sqrt/sin/cos
     assert abs(got.mean()) < 0.03 and abs(got.std() - 1) < 0.03
 
 
