@@ -124,9 +124,9 @@ def main():
     t0 = time.perf_counter()
     smp.step(args.steps)
     if world > 1 and not args.no_moments:
+        from lmc_atomi_amd.sharding import allreduce_moments
         s1, s2, cnt = smp.moments()
-        packed = torch.stack([s1, s2])
-        dist.all_reduce(packed)                              # RCCL over xGMI: posterior mean/var accumulators
+        s1, s2, cnt = allreduce_moments(s1, s2, cnt)         # RCCL over xGMI: posterior mean/var accumulators
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:

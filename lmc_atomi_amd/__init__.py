@@ -9,7 +9,10 @@ from .proximal import L1, L2, L21, TV, ProxOperator, fgp_betas
 from .algs import (MYULAResult, MYULASampler, MoreauYosidaUnadjustedLangevin, mean_var_from_moments,
                    set_step_variant)
 
+from .sharding import allreduce_moments, chain_shard, posterior_mean_var, sharded_myula
+
 __all__ = [
+    "allreduce_moments", "chain_shard", "posterior_mean_var", "sharded_myula",
     "LMCError", "Convolve2D", "Diagonal", "Gradient", "Identity", "LinearOperator",
     "L1", "L2", "L21", "TV", "ProxOperator", "fgp_betas",
     "MYULASampler", "MYULAResult", "MoreauYosidaUnadjustedLangevin", "mean_var_from_moments", "set_step_variant",

@@ -1,0 +1,66 @@
+"""Chains across GPUs: one process per GPU, chains sharded by contiguous ranges of GLOBAL chain ids,
+no data-path collective; the single collective is one all-reduce (RCCL over xGMI through
+``torch.distributed``, backend "nccl"; "gloo" in the CPU tests) of the posterior moment images
+{sum x, sum x^2, count} (2*H*W float64 + 1 scalar: 4 MiB at 512x512).
+
+The reference runs exactly one chain in one process (algs.py:564); this module is what lets the
+drop-in scale it out.  Because the device noise is keyed by (seed, iteration, global chain id, pixel)
+every chain's trajectory is independent of the number of ranks.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def chain_shard(n_total: int, world: int, rank: int):
+    """(offset, count) of the contiguous block of global chain ids owned by ``rank``."""
+    if not (0 <= rank < world):
+        raise ValueError("rank outside world")
+    base, rem = divmod(int(n_total), int(world))
+    count = base + (1 if rank < rem else 0)
+    offset = rank * base + min(rank, rem)
+    return offset, count
+
+
+def allreduce_moments(s1: torch.Tensor, s2: torch.Tensor, count: int, group=None):
+    """Sum the per-rank accumulators over all ranks.  Returns (sum, sumsq, count) of the whole job.
+    One collective call: the two images and the count travel in one packed float64 buffer."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return s1, s2, int(count)
+    n = s1.numel()
+    packed = torch.empty(2 * n + 1, dtype=torch.float64, device=s1.device)
+    packed[:n] = s1.reshape(-1)
+    packed[n:2 * n] = s2.reshape(-1)
+    packed[2 * n] = float(count)
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    return packed[:n].reshape(s1.shape), packed[n:2 * n].reshape(s2.shape), int(round(float(packed[2 * n])))
+
+
+def posterior_mean_var(s1, s2, count):
+    mean = s1 / count
+    return mean, s2 / count - mean * mean
+
+
+def sharded_myula(proxf, proxg, dims, n_chains_total, x0, tau, gamma, epsg=1.0, niter=10, seed=0,
+                  burn_in=0, thin=1, group=None, device=None):
+    """Run ``n_chains_total`` MYULA chains split over the ranks of the default process group (or run
+    them all here when torch.distributed is not initialised) and return the job-wide posterior
+    (mean, var, count) plus this rank's final states."""
+    import torch.distributed as dist
+    from .algs import MYULASampler
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    offset, count = chain_shard(n_chains_total, world, rank)
+    smp = MYULASampler(proxf, proxg, dims, n_chains=count, tau=tau, gamma=gamma, epsg=epsg, seed=seed,
+                       chain_offset=offset, moments=True, burn_in=burn_in, thin=thin, device=device)
+    try:
+        smp.set_state(x0)
+        smp.step(niter)
+        s1, s2, cnt = smp.moments()
+        state = smp.get_state()
+    finally:
+        smp.close()
+    s1, s2, cnt = allreduce_moments(s1, s2, cnt, group)
+    mean, var = posterior_mean_var(s1, s2, cnt)
+    return mean, var, cnt, state
