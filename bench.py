@@ -97,6 +97,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import lmc_atomi_amd as la
+    if os.environ.get("LMC_VARIANT"):                # A/B runs of the step-kernel variants (scripts/bench_variants.py)
+        la.set_step_variant(os.environ["LMC_VARIANT"])
 
     H = W = args.size
     C = args.chains

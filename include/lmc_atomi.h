@@ -188,7 +188,7 @@ int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_lau
 const char* lmc_sampler_kernel_name(const lmc_sampler* s);
 
 /* Step-kernel variant used by lmc_sampler_step / lmc_fused_eval: 0 = auto (default), 1 = LDS-tiled,
- * 2 = streaming register pipeline.  Returns the previous setting (>= 0) or a negative lmc_status.
+ * 2 = streaming register pipeline (one wave group), 3 = the same pipeline split over two wave groups.  Returns the previous setting (>= 0) or a negative lmc_status.
  * Both variants compute the same update; the switch exists for A/B tests and profiles. */
 int lmc_set_step_variant(int32_t variant);
 

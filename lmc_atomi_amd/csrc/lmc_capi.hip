@@ -144,15 +144,20 @@ void sanitize_pointers(lmc::StepArgs& A) {
   if (!A.noise) A.noise = A.x_in;
 }
 
-int g_variant = 0;  // 0 auto, 1 tile, 2 stream
+int g_variant = 0;  // 0 auto, 1 tile, 2 stream, 3 split
 
-// Picks the step-kernel variant: the streaming register pipeline when it covers the configuration
-// (W <= 512, separable blur, supported K), else the LDS-tiled kernel.
+// Picks the step-kernel variant.  auto: the split streaming pipeline (two wave groups, 4 waves/SIMD) when
+// it covers the configuration (W <= 512, separable blur <= 7x7, supported K), else the LDS-tiled kernel.
 hipError_t launch_step(const lmc::StepArgs& A, hipStream_t st, const char** name) {
-  const bool can_stream = lmc::stream_supported(A);
-  const bool use_stream = g_variant == 2 ? true : (g_variant == 1 ? false : can_stream);
-  if (use_stream) {
-    if (!can_stream) return hipErrorInvalidConfiguration;
+  int v = g_variant;
+  if (v == 0) v = lmc::split_supported(A) ? 3 : (lmc::stream_supported(A) ? 2 : 1);
+  if (v == 3) {
+    if (!lmc::split_supported(A)) return hipErrorInvalidConfiguration;
+    if (name) *name = "myula_step_split_kernel";
+    return lmc::launch_step_split(A, st);
+  }
+  if (v == 2) {
+    if (!lmc::stream_supported(A)) return hipErrorInvalidConfiguration;
     if (name) *name = "myula_step_stream_kernel";
     return lmc::launch_step_stream(A, st);
   }
@@ -477,7 +482,7 @@ int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_lau
 const char* lmc_sampler_kernel_name(const lmc_sampler* s) { return s ? s->kernel_name.c_str() : ""; }
 
 int lmc_set_step_variant(int32_t variant) {
-  if (variant < 0 || variant > 2) return fail(LMC_E_INVALID, "variant must be 0 (auto), 1 (tile) or 2 (stream)");
+  if (variant < 0 || variant > 3) return fail(LMC_E_INVALID, "variant must be 0 (auto), 1 (tile), 2 (stream) or 3 (split)");
   const int prev = g_variant;
   g_variant = variant;
   return prev;

@@ -79,4 +79,33 @@ __device__ __forceinline__ int xcd_logical_block(int b, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
+// ---- shared by the streaming step kernels ---------------------------------------------------------
+constexpr int kPad = 8;  // zero columns on both sides of LDS rows (>= kMaxBlur - 1)
+#ifdef LMC_BOUNDS_CHECK   // debug build: out-of-range global accesses are recorded and skipped, never issued
+static __device__ long long lmc_dbg[8];
+__device__ __forceinline__ float ld_chk(const float* base, long long idx, long long n, int tag) {
+  if (base == nullptr || idx < 0 || idx >= n) { lmc_dbg[0] = tag; lmc_dbg[1] = idx; lmc_dbg[2] = n; lmc_dbg[3] = (long long)base; return 0.f; }
+  return base[idx];
+}
+__device__ __forceinline__ void st_chk(float* base, long long idx, long long n, float v, int tag) {
+  if (base == nullptr || idx < 0 || idx >= n) { lmc_dbg[0] = tag; lmc_dbg[1] = idx; lmc_dbg[2] = n; lmc_dbg[3] = (long long)base; return; }
+  base[idx] = v;
+}
+#define LD(base, idx, n, tag) ld_chk(base, (long long)(idx), (long long)(n), tag)
+#define ST(base, idx, n, v, tag) st_chk(base, (long long)(idx), (long long)(n), v, tag)
+#else
+#define LD(base, idx, n, tag) (base)[idx]
+#define ST(base, idx, n, v, tag) (base)[idx] = (v)
+#endif
+
+__device__ __forceinline__ float dpp_from_left(float v, float edge) {   // lane i <- v[i-1]; lane 0 <- edge
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
+                                                              __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_right(float v, float edge) {  // lane i <- v[i+1]; lane 63 <- edge
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
+                                                              __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+
 }  // namespace lmc

@@ -24,37 +24,10 @@
 
 namespace lmc {
 
-constexpr int kPad = 8;  // zero columns on both sides of LDS rows (>= kMaxBlur - 1)
 #ifndef LMC_SCHED_GROUP
 #define LMC_SCHED_GROUP 2
 #endif
 constexpr int SCHED_GROUP = LMC_SCHED_GROUP;  // TV stages per scheduling region (0 = unrestricted)
-
-#ifdef LMC_BOUNDS_CHECK   // debug build: out-of-range global accesses are recorded and skipped, never issued
-__device__ long long lmc_dbg[8];
-__device__ __forceinline__ float ld_chk(const float* base, long long idx, long long n, int tag) {
-  if (base == nullptr || idx < 0 || idx >= n) { lmc_dbg[0] = tag; lmc_dbg[1] = idx; lmc_dbg[2] = n; lmc_dbg[3] = (long long)base; return 0.f; }
-  return base[idx];
-}
-__device__ __forceinline__ void st_chk(float* base, long long idx, long long n, float v, int tag) {
-  if (base == nullptr || idx < 0 || idx >= n) { lmc_dbg[0] = tag; lmc_dbg[1] = idx; lmc_dbg[2] = n; lmc_dbg[3] = (long long)base; return; }
-  base[idx] = v;
-}
-#define LD(base, idx, n, tag) ld_chk(base, (long long)(idx), (long long)(n), tag)
-#define ST(base, idx, n, v, tag) st_chk(base, (long long)(idx), (long long)(n), v, tag)
-#else
-#define LD(base, idx, n, tag) (base)[idx]
-#define ST(base, idx, n, v, tag) (base)[idx] = (v)
-#endif
-
-__device__ __forceinline__ float dpp_from_left(float v, float edge) {   // lane i <- v[i-1]; lane 0 <- edge
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
-                                                              __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float dpp_from_right(float v, float edge) {  // lane i <- v[i+1]; lane 63 <- edge
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
-                                                              __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
-}
 
 template <int K>
 struct StreamGeom {
@@ -319,7 +292,11 @@ __global__ __launch_bounds__(64 * NW, 2) void myula_step_stream_kernel(const Ste
   int tm = 0;
   for (int t0 = 0; t0 < T; t0 += 4) {
     // predicate-free body needs: o >= 0, row t+2 < H (prefetch), residual rows and y prefetch inside
+#ifdef LMC_NO_STEADY
+    const bool steady = false;
+#else
     const bool steady = (t0 >= t_lo) && (t0 + 3 + 2 < H);
+#endif
     if (steady) stream_group<K, NW, KT, false>(A, t0, tm, c, S);
     else stream_group<K, NW, KT, true>(A, t0, tm, c, S);
   }
@@ -377,7 +354,7 @@ static hipError_t launch_kt(const StepArgs& a, int KT, hipStream_t st) {
 }
 
 // Rank-1 factorisation h = u v^T of the blur taps (u: kh, v: kw).  Returns false if h is not separable.
-static bool separate_taps(const BlurTaps& T, float* u, float* v) {
+bool separate_blur_taps(const BlurTaps& T, float* u, float* v) {
   int pa = 0, pb = 0;
   float best = 0.f;
   for (int a = 0; a < T.kh; ++a)
@@ -419,7 +396,7 @@ bool stream_supported(const StepArgs& a) {
   if (a.data_kind == LMC_DATA_BLUR) {
     if (a.blur.kh > 7 || a.blur.kw > 7) return false;
     float u[kMaxBlur], v[kMaxBlur];
-    if (!separate_taps(a.blur, u, v)) return false;
+    if (!separate_blur_taps(a.blur, u, v)) return false;
   }
   return true;
 }
@@ -428,7 +405,7 @@ hipError_t launch_step_stream(StepArgs a, hipStream_t st) {
   int KT = 5;
   if (a.data_kind == LMC_DATA_BLUR) {
     float u[kMaxBlur] = {0}, v[kMaxBlur] = {0};
-    if (!separate_taps(a.blur, u, v)) return hipErrorInvalidConfiguration;
+    if (!separate_blur_taps(a.blur, u, v)) return hipErrorInvalidConfiguration;
     for (int i = 0; i < kMaxBlur; ++i) { a.blur.h[i] = u[i]; a.blur.h[kMaxBlur + i] = v[i]; }  // zero padded
     KT = (a.blur.kh > a.blur.kw ? a.blur.kh : a.blur.kw) <= 5 ? 5 : 7;
   }

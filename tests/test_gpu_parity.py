@@ -33,7 +33,7 @@ def la():
 @pytest.fixture(autouse=True, params=["tile", "auto"])
 def variant(request, la):
     """Every test runs twice: with the LDS-tiled step kernel forced, and with the default choice
-    (the streaming register-pipeline kernel wherever it covers the configuration)."""
+    (the split streaming register-pipeline kernel wherever it covers the configuration)."""
     prev = la.set_step_variant(request.param)
     yield request.param
     la.set_step_variant(prev)
@@ -212,7 +212,7 @@ def test_stream_and_tile_variants_agree(la):
         pg = la.TV(shape, sigma=0.3, niter=niter)
         x0 = img[None] + rng.normal(0, 10, (2,) + shape)
         outs = {}
-        for v in ("tile", "stream"):
+        for v in ("tile", "stream", "split"):
             la.set_step_variant(v)
             smp = la.MYULASampler(pf, pg, shape, n_chains=2, tau=0.1125, gamma=0.5625, seed=5)
             smp.set_state(x0)
@@ -221,6 +221,25 @@ def test_stream_and_tile_variants_agree(la):
             assert v in smp.kernel_name
             smp.close()
         assert rel(outs["stream"], outs["tile"]) < 2e-6, (shape, rel(outs["stream"], outs["tile"]))
+        assert rel(outs["split"], outs["tile"]) < 2e-6, (shape, rel(outs["split"], outs["tile"]))
+    # other data terms / priors through all three kernels
+    shape = (45, 150)
+    img, h, y = synth(*shape, seed=3)
+    mask = (rng.uniform(size=shape) < 0.5).astype(np.float64)
+    cases = [(la.L2(b=y, sigma=1.7, dims=shape), la.L1(sigma=0.3)),
+             (la.L2(Op=la.Diagonal(mask, dims=shape), b=mask * y, sigma=1.7, dims=shape), la.TV(shape, sigma=0.3, niter=5)),
+             (la.L2(Op=la.Convolve2D(shape, h), b=y, sigma=1.7), la.L2(sigma=0.05)),
+             (la.L2(Op=la.Convolve2D(shape, h), b=y, sigma=1.7), None)]
+    for pf, pg in cases:
+        outs = {}
+        for v in ("tile", "stream", "split"):
+            la.set_step_variant(v)
+            smp = la.MYULASampler(pf, pg, shape, n_chains=3, tau=0.1125, gamma=0.5625, seed=8, chain_offset=5)
+            smp.set_state(img)
+            smp.step(4)
+            outs[v] = smp.get_state().cpu().numpy()
+            smp.close()
+        assert rel(outs["stream"], outs["tile"]) < 2e-6 and rel(outs["split"], outs["tile"]) < 2e-6
     # a configuration the streaming kernel does not cover (K = 16): forcing it is an error, the default falls back
     shape = (40, 96)
     img, h, y = synth(*shape, seed=1)
