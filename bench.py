@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--width", type=int, default=0, help="image width if not square (experiments)")
     ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
     ap.add_argument("--tv-iters", type=int, default=10)
     ap.add_argument("--prior", default="tv", choices=["tv", "l2", "l1"])
@@ -101,6 +102,8 @@ def main():
         la.set_step_variant(os.environ["LMC_VARIANT"])
 
     H = W = args.size
+    if args.width:
+        W = args.width
     C = args.chains
     sigma, tau_reg = 0.75, 0.3                       # prox_lmc_deconv.py:40 defaults
     gamma, tau = sigma ** 2, 0.2 * sigma ** 2        # prox_lmc_deconv.py:92-94

@@ -1,5 +1,6 @@
 // Device-side building blocks: Philox4x32-10, Box-Muller, wave/block reductions.
 #pragma once
+#include <type_traits>
 #include "lmc_common.h"
 
 namespace lmc {
@@ -107,5 +108,29 @@ __device__ __forceinline__ float dpp_from_right(float v, float edge) {  // lane 
                                                               __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
+// ---- wave-edge ("ghost") gather: one LDS store per wave and direction instead of one per stage ------
+// gather_lane0<N>(acc, v): lane N of the result = lane 0 of v (other lanes of row 0 at or above N inside
+// N's bank are overwritten too and must be fixed by later calls with larger N; lanes below N keep acc).
+template <int N>
+__device__ __forceinline__ float gather_lane0(float acc, float v) {
+  static_assert(N >= 1 && N <= 15, "row_shr distance");
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, acc), __builtin_bit_cast(int, v),
+                                                              0x110 + N, 0x1, 1 << (N >> 2), false));
+}
+// gather_lane63<N>(acc, v): lane 63-N of the result = lane 63 of v (row 3, row_shl:N).
+template <int N>
+__device__ __forceinline__ float gather_lane63(float acc, float v) {
+  static_assert(N >= 1 && N <= 15, "row_shl distance");
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, acc), __builtin_bit_cast(int, v),
+                                                              0x100 + N, 0x8, 1 << ((15 - N) >> 2), false));
+}
+
+template <int I, int End, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < End) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, End>(f);
+  }
+}
 
 }  // namespace lmc

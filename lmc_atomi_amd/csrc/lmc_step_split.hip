@@ -32,10 +32,24 @@ struct SplitLds {
   static constexpr int o_rrow = o_xring + 2 * RB * BWP;   // [2][BWP]  residual row
   static constexpr int o_hand = o_rrow + 2 * BWP;         // [2][4][BWP] stage-KA outputs rr, ss, p, q
   static constexpr int o_garr = o_hand + 8 * BWP;         // [2][BWP]  gradient of the output row
-  static constexpr int o_gsol = o_garr + 2 * BWP;         // [2][K+2][NW]
-  static constexpr int o_gss = o_gsol + 2 * (K + 2) * NW; // [2][K+2][NW]
-  static constexpr int total = o_gss + 2 * (K + 2) * NW;
+  // wave-edge exchange: per parity NW+1 blocks of 64 slots.  sol: lane 0 of wave w -> block w, read by wave
+  // w-1 as block (w-1)+1, slot k;  ss: lane 63 of wave w -> block w+1, read by wave w+1, slot 63-k.
+  // Each wave group has its own arrays (both store all 64 lanes of a block every tick).
+  static constexpr int GB = 64 * (NW + 1);
+  static constexpr int o_gsol = o_garr + 2 * BWP;         // [group][2][NW+1][64]
+  static constexpr int o_gss = o_gsol + 4 * GB;           // [group][2][NW+1][64]
+  static constexpr int total = o_gss + 4 * GB;
 };
+
+// Broadcast-load ghost slots [4*V0 .. 4*V1+3] of a 64-slot block with 16-byte LDS reads (one per 4 stages).
+template <int V0, int V1>
+__device__ __forceinline__ void load_ghost(const float* blk, float (&g)[16]) {
+  static_for<V0, V1 + 1>([&](auto vv) {
+    constexpr int v = decltype(vv)::value;
+    const float4 q = *reinterpret_cast<const float4*>(blk + 4 * v);
+    g[4 * v + 0] = q.x; g[4 * v + 1] = q.y; g[4 * v + 2] = q.z; g[4 * v + 3] = q.w;
+  });
+}
 
 struct SplitCtx {
   float* lds;
@@ -83,8 +97,11 @@ __device__ __forceinline__ void split_tick_a(const StepArgs& A, const int t, con
 
   if constexpr (KA > 0) {
     const float gam = A.tv.gamma, cstep = A.tv.c;
-    const float* gssr = c.lds + L::o_gss + (P ^ 1) * (K + 2) * NW + c.wave;
-    const float* gsolr = c.lds + L::o_gsol + (P ^ 1) * (K + 2) * NW + c.wave;
+    // ghost values of the previous tick: sol of the right neighbour wave's lane 0 (slot k of block wave+1),
+    // ss of the left neighbour wave's lane 63 (slot 63-k of block wave, i.e. index 15-k of its last 16 slots)
+    float gsolv[16], gssv[16];
+    load_ghost<0, KA / 4>(c.lds + L::o_gsol + (P ^ 1) * L::GB + (c.wave + 1) * 64, gsolv);
+    if constexpr (KA > 1) load_ghost<(15 - (KA - 1)) / 4, 3>(c.lds + L::o_gss + (P ^ 1) * L::GB + c.wave * 64 + 48, gssv);
 #pragma unroll
     for (int k = KA; k >= 1; --k) {
       const float xa = xb[(G::RB - (G::E + 2 * k)) * BWP];
@@ -93,12 +110,20 @@ __device__ __forceinline__ void split_tick_a(const StepArgs& A, const int t, con
         sol = xa;
       } else {
         const float ssc = S.ss[k - 1][P ^ 1];
-        const float ssl = dpp_from_left(ssc, gssr[(k - 1) * NW]);
+#ifdef LMC_EXP_NOGHOST
+        const float ssl = dpp_from_left(ssc, 0.f);
+#else
+        const float ssl = dpp_from_left(ssc, gssv[15 - (k - 1)]);
+#endif
         sol = fmaf(-gam, (S.rr[k - 1][P ^ 1] - S.rr[k - 1][P]) + (ssc - ssl), xa);
       }
       S.sol[k][P] = sol;
       const float solb = S.sol[k][P ^ 1];
-      const float solr = dpp_from_right(solb, gsolr[k * NW]);
+#ifdef LMC_EXP_NOGHOST
+      const float solr = dpp_from_right(solb, 0.f);
+#else
+      const float solr = dpp_from_right(solb, gsolv[k]);
+#endif
       float cdown = cstep;
       if (EDGE) {
         const int b = t - G::E - 2 * k - 1;
@@ -121,18 +146,17 @@ __device__ __forceinline__ void split_tick_a(const StepArgs& A, const int t, con
       if ((k % LMC_SPLIT_SCHED) == 0) __builtin_amdgcn_sched_barrier(0);
 #endif
     }
-    if (NW > 1) {
-      if (c.lane == 0 && c.wave > 0) {
-        float* g = c.lds + L::o_gsol + P * (K + 2) * NW + c.wave - 1;
-#pragma unroll
-        for (int k = 1; k <= KA; ++k) g[k * NW] = S.sol[k][P];
-      }
-      if (KA > 1 && c.lane == 63 && c.wave < NW - 1) {
-        float* g = c.lds + L::o_gss + P * (K + 2) * NW + c.wave + 1;
-#pragma unroll
-        for (int k = 1; k < KA; ++k) g[k * NW] = S.ss[k][P];
+#ifndef LMC_EXP_NOGHOST
+    if (NW > 1) {   // one store per direction: stage values gathered into lanes by DPP, all lanes store
+      float gs = 0.f, gq = 0.f;
+      static_for<1, KA + 1>([&](auto kk) { constexpr int k = decltype(kk)::value; gs = gather_lane0<k>(gs, S.sol[k][P]); });
+      c.lds[L::o_gsol + P * L::GB + c.wave * 64 + c.lane] = gs;
+      if constexpr (KA > 1) {
+        static_for<1, KA>([&](auto kk) { constexpr int k = decltype(kk)::value; gq = gather_lane63<k>(gq, S.ss[k][P]); });
+        c.lds[L::o_gss + P * L::GB + (c.wave + 1) * 64 + c.lane] = gq;
       }
     }
+#endif
   }
 
   // blur gradient pipeline, one row ahead of the output: g[o+1] -> garr[P] (group B reads it next tick)
@@ -203,8 +227,11 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
     S.hq[P ^ 1] = hb[3 * BWP];
     const float hssl = hb[BWP - 1];
     const float gam = A.tv.gamma, cstep = A.tv.c;
-    const float* gssr = c.lds + L::o_gss + (P ^ 1) * (K + 2) * NW + c.wave;
-    const float* gsolr = c.lds + L::o_gsol + (P ^ 1) * (K + 2) * NW + c.wave;
+    float gsolv[16], gssv[16];
+    if constexpr (K > KA) {
+      load_ghost<(KA + 1) / 4, K / 4>(c.lds + L::o_gsol + (2 + (P ^ 1)) * L::GB + (c.wave + 1) * 64, gsolv);
+      load_ghost<(15 - K) / 4, (15 - (KA + 1)) / 4>(c.lds + L::o_gss + (2 + (P ^ 1)) * L::GB + c.wave * 64 + 48, gssv);
+    }
 #pragma unroll
     for (int k = K + 1; k > KA; --k) {
       const float xa = xb[(G::RB - (G::E + 2 * k)) * BWP];
@@ -213,7 +240,11 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
         rr1 = S.hrr[P ^ 1]; rr2 = S.hrr[P]; ssc = S.hss[P ^ 1]; ssl = hssl;
       } else {
         rr1 = S.rr[k - 1][P ^ 1]; rr2 = S.rr[k - 1][P]; ssc = S.ss[k - 1][P ^ 1];
-        ssl = dpp_from_left(ssc, gssr[(k - 1) * NW]);
+#ifdef LMC_EXP_NOGHOST
+        ssl = dpp_from_left(ssc, 0.f);
+#else
+        ssl = dpp_from_left(ssc, gssv[15 - (k - 1)]);
+#endif
       }
       const float sol = fmaf(-gam, (rr1 - rr2) + (ssc - ssl), xa);
       S.sol[k][P] = sol;
@@ -221,7 +252,11 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
         prox_o = sol;
       } else {
         const float solb = S.sol[k][P ^ 1];
-        const float solr = dpp_from_right(solb, gsolr[k * NW]);
+#ifdef LMC_EXP_NOGHOST
+        const float solr = dpp_from_right(solb, 0.f);
+#else
+        const float solr = dpp_from_right(solb, gsolv[k]);
+#endif
         float cdown = cstep;
         if (EDGE) {
           const int b = t - G::E - 2 * k - 1;
@@ -244,18 +279,15 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
       if ((k % LMC_SPLIT_SCHED) == 0) __builtin_amdgcn_sched_barrier(0);
 #endif
     }
-    if (NW > 1 && K > KA) {
-      if (c.lane == 0 && c.wave > 0) {
-        float* g = c.lds + L::o_gsol + P * (K + 2) * NW + c.wave - 1;
-#pragma unroll
-        for (int k = KA + 1; k <= K; ++k) g[k * NW] = S.sol[k][P];
-      }
-      if (c.lane == 63 && c.wave < NW - 1) {
-        float* g = c.lds + L::o_gss + P * (K + 2) * NW + c.wave + 1;
-#pragma unroll
-        for (int k = KA + 1; k <= K; ++k) g[k * NW] = S.ss[k][P];
-      }
+#ifndef LMC_EXP_NOGHOST
+    if constexpr (NW > 1 && K > KA) {
+      float gs = 0.f, gq = 0.f;
+      static_for<KA + 1, K + 1>([&](auto kk) { constexpr int k = decltype(kk)::value; gs = gather_lane0<k>(gs, S.sol[k][P]); });
+      c.lds[L::o_gsol + (2 + P) * L::GB + c.wave * 64 + c.lane] = gs;
+      static_for<KA + 1, K + 1>([&](auto kk) { constexpr int k = decltype(kk)::value; gq = gather_lane63<k>(gq, S.ss[k][P]); });
+      c.lds[L::o_gss + (2 + P) * L::GB + (c.wave + 1) * 64 + c.lane] = gq;
     }
+#endif
   }
 
   constexpr int NI = ((U - G::D) % 4 + 4) % 4;  // == o & 3
