@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--prior", default="tv", choices=["tv", "l2", "l1"])
     ap.add_argument("--thin", type=int, default=1, help="accumulate posterior moments every thin-th iteration")
     ap.add_argument("--no-moments", action="store_true")
+    ap.add_argument("--data", default="blur", choices=["blur", "identity"], help="data term (experiments)")
+    ap.add_argument("--noise", default="philox", choices=["philox", "none"], help="noise source (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chains", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=20)
@@ -108,11 +110,14 @@ def main():
     sigma, tau_reg = 0.75, 0.3                       # prox_lmc_deconv.py:40 defaults
     gamma, tau = sigma ** 2, 0.2 * sigma ** 2        # prox_lmc_deconv.py:92-94
     u, h, y = synth_problem(H, W, sigma)
-    pf = la.L2(Op=la.Convolve2D((H, W), h, offset=(2, 2)), b=y, sigma=1 / sigma ** 2)
+    if args.data == "blur":
+        pf = la.L2(Op=la.Convolve2D((H, W), h, offset=(2, 2)), b=y, sigma=1 / sigma ** 2)
+    else:
+        pf = la.L2(b=y, sigma=1 / sigma ** 2, dims=(H, W))
     pg = {"tv": la.TV((H, W), sigma=tau_reg, niter=args.tv_iters), "l2": la.L2(sigma=0.05),
           "l1": la.L1(sigma=tau_reg)}[args.prior]
     smp = la.MYULASampler(pf, pg, (H, W), n_chains=C, tau=tau, gamma=gamma, seed=0, chain_offset=rank * C,
-                          moments=not args.no_moments, burn_in=0, thin=args.thin)
+                          moments=not args.no_moments, burn_in=0, thin=args.thin, noise=args.noise)
     smp.set_state(np.zeros((H, W), dtype=np.float32))        # x0 = 0 (prox_lmc_deconv.py:135)
 
     def sync_all():

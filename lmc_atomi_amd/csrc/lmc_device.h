@@ -108,21 +108,33 @@ __device__ __forceinline__ float dpp_from_right(float v, float edge) {  // lane 
                                                               __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
-// ---- wave-edge ("ghost") gather: one LDS store per wave and direction instead of one per stage ------
-// gather_lane0<N>(acc, v): lane N of the result = lane 0 of v (other lanes of row 0 at or above N inside
-// N's bank are overwritten too and must be fixed by later calls with larger N; lanes below N keep acc).
+// ---- horizontal neighbours at DPP-row (16-lane) granularity -----------------------------------------
+// wave_shr / wave_shl DPP moves cost ~12 cycles per wave on gfx950 (measured, scripts/ubench/stage_mix.hip);
+// row_shr:1 / row_shl:1 run at the plain VALU rate.  So neighbours inside a 16-lane row come from row
+// shifts, and the lane at each row's end takes the value its neighbour row published in LDS one tick
+// earlier ("ghost": the values used are one tick old anyway).
+__device__ __forceinline__ float row_from_left(float v, float edge) {   // lane i <- v[i-1]; first lane of each row <- edge
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
+                                                              __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_from_right(float v, float edge) {  // lane i <- v[i+1]; last lane of each row <- edge
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
+                                                              __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));
+}
+// gather_first<N>(acc, v): in every row, lane N of the result = first lane of v (lanes above N inside N's
+// bank are overwritten too and are fixed by later calls with larger N; lanes below N keep acc).
 template <int N>
-__device__ __forceinline__ float gather_lane0(float acc, float v) {
+__device__ __forceinline__ float gather_first(float acc, float v) {
   static_assert(N >= 1 && N <= 15, "row_shr distance");
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, acc), __builtin_bit_cast(int, v),
-                                                              0x110 + N, 0x1, 1 << (N >> 2), false));
+                                                              0x110 + N, 0xf, 1 << (N >> 2), false));
 }
-// gather_lane63<N>(acc, v): lane 63-N of the result = lane 63 of v (row 3, row_shl:N).
+// gather_last<N>(acc, v): in every row, lane 15-N of the result = last lane of v (row_shl:N).
 template <int N>
-__device__ __forceinline__ float gather_lane63(float acc, float v) {
+__device__ __forceinline__ float gather_last(float acc, float v) {
   static_assert(N >= 1 && N <= 15, "row_shl distance");
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, acc), __builtin_bit_cast(int, v),
-                                                              0x100 + N, 0x8, 1 << ((15 - N) >> 2), false));
+                                                              0x100 + N, 0xf, 1 << ((15 - N) >> 2), false));
 }
 
 template <int I, int End, class F>

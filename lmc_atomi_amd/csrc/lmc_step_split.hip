@@ -16,6 +16,15 @@
 
 namespace lmc {
 
+#ifdef LMC_EXP_NOLDS   // timing experiment: no LDS traffic at all (results are wrong)
+__device__ __forceinline__ float exp_keep(float v) { asm volatile("" : "+v"(v)); return v; }
+#define LR(ptr_expr, alt) exp_keep(alt)
+#define LW(lhs, val) do { float v_ = (val); asm volatile("" ::"v"(v_)); } while (0)
+#else
+#define LR(ptr_expr, alt) (ptr_expr)
+#define LW(lhs, val) (lhs) = (val)
+#endif
+
 template <int K>
 struct SplitGeom {
   static constexpr int D = (2 * K + 2 > 10) ? 2 * K + 2 : 10;  // output row lag: o = t - D
@@ -32,8 +41,9 @@ struct SplitLds {
   static constexpr int o_rrow = o_xring + 2 * RB * BWP;   // [2][BWP]  residual row
   static constexpr int o_hand = o_rrow + 2 * BWP;         // [2][4][BWP] stage-KA outputs rr, ss, p, q
   static constexpr int o_garr = o_hand + 8 * BWP;         // [2][BWP]  gradient of the output row
-  // wave-edge exchange: per parity NW+1 blocks of 64 slots.  sol: lane 0 of wave w -> block w, read by wave
-  // w-1 as block (w-1)+1, slot k;  ss: lane 63 of wave w -> block w+1, read by wave w+1, slot 63-k.
+  // row-edge exchange: per parity a linear array of 64*(NW+1) slots, 16 per DPP row.
+  //   sol: first lane of (wave w, row r), stage k -> slot 64w + 16r + k      ; read by the row to its left
+  //   ss : last lane of (wave w, row r), stage k  -> slot 64(w+1) + 16r + 15-k; read by the row to its right
   // Each wave group has its own arrays (both store all 64 lanes of a block every tick).
   static constexpr int GB = 64 * (NW + 1);
   static constexpr int o_gsol = o_garr + 2 * BWP;         // [group][2][NW+1][64]
@@ -46,7 +56,11 @@ template <int V0, int V1>
 __device__ __forceinline__ void load_ghost(const float* blk, float (&g)[16]) {
   static_for<V0, V1 + 1>([&](auto vv) {
     constexpr int v = decltype(vv)::value;
+#ifdef LMC_EXP_NOLDS
+    const float4 q = {1.f, 2.f, 3.f, 4.f};
+#else
     const float4 q = *reinterpret_cast<const float4*>(blk + 4 * v);
+#endif
     g[4 * v + 0] = q.x; g[4 * v + 1] = q.y; g[4 * v + 2] = q.z; g[4 * v + 3] = q.w;
   });
 }
@@ -63,7 +77,7 @@ template <int K, int KT>
 struct StateA {
   static constexpr int KA = SplitGeom<K>::KA;
   float rr[KA + 1][2], ss[KA + 1][2], p[KA + 1][2], q[KA + 1][2], sol[KA + 2][2];
-  float hxw[KT - 1], hrw[KT - 1], xpre[2], ypre[2];
+  float hxw[KT - 1], hrw[KT - 1], xpre[4], ypre[4];   // x / y rows in flight: fetched 4 ticks ahead, slot t & 3
 };
 
 template <int K>
@@ -85,14 +99,14 @@ __device__ __forceinline__ void split_tick_a(const StepArgs& A, const int t, con
   float* const xb = c.lds + L::o_xring + tm * BWP + kPad + c.col;  // row t-cc is xb[(RB - cc) * BWP]
 
   {  // row t arrives: publish it (twice) in the x ring; fetch row t+2
-    float xv = S.xpre[P];
+    float xv = S.xpre[U];
     if (EDGE) xv = (t < H) ? xv : 0.f;
     xv = incol ? xv : 0.f;
-    xb[0] = xv;
-    xb[G::RB * BWP] = xv;
-    int tn = t + 2;
+    LW(xb[0], xv);
+    LW(xb[G::RB * BWP], xv);
+    int tn = t + 4;
     if (EDGE) tn = tn < H ? tn : H - 1;
-    S.xpre[P] = LD(c.xin, (size_t)tn * W + c.colc, (size_t)H * W, 1);
+    S.xpre[U] = LD(c.xin, (size_t)tn * W + c.colc, (size_t)H * W, 1);
   }
 
   if constexpr (KA > 0) {
@@ -100,29 +114,29 @@ __device__ __forceinline__ void split_tick_a(const StepArgs& A, const int t, con
     // ghost values of the previous tick: sol of the right neighbour wave's lane 0 (slot k of block wave+1),
     // ss of the left neighbour wave's lane 63 (slot 63-k of block wave, i.e. index 15-k of its last 16 slots)
     float gsolv[16], gssv[16];
-    load_ghost<0, KA / 4>(c.lds + L::o_gsol + (P ^ 1) * L::GB + (c.wave + 1) * 64, gsolv);
-    if constexpr (KA > 1) load_ghost<(15 - (KA - 1)) / 4, 3>(c.lds + L::o_gss + (P ^ 1) * L::GB + c.wave * 64 + 48, gssv);
+    load_ghost<0, KA / 4>(c.lds + L::o_gsol + (P ^ 1) * L::GB + c.wave * 64 + (c.lane & 48) + 16, gsolv);
+    if constexpr (KA > 1) load_ghost<(15 - (KA - 1)) / 4, 3>(c.lds + L::o_gss + (P ^ 1) * L::GB + c.wave * 64 + (c.lane & 48) + 48, gssv);
 #pragma unroll
     for (int k = KA; k >= 1; --k) {
-      const float xa = xb[(G::RB - (G::E + 2 * k)) * BWP];
+      const float xa = LR(xb[(G::RB - (G::E + 2 * k)) * BWP], S.xpre[0] + (float)k);
       float sol;
       if (k == 1) {
         sol = xa;
       } else {
         const float ssc = S.ss[k - 1][P ^ 1];
 #ifdef LMC_EXP_NOGHOST
-        const float ssl = dpp_from_left(ssc, 0.f);
+        const float ssl = row_from_left(ssc, 0.f);
 #else
-        const float ssl = dpp_from_left(ssc, gssv[15 - (k - 1)]);
+        const float ssl = row_from_left(ssc, gssv[15 - (k - 1)]);
 #endif
         sol = fmaf(-gam, (S.rr[k - 1][P ^ 1] - S.rr[k - 1][P]) + (ssc - ssl), xa);
       }
       S.sol[k][P] = sol;
       const float solb = S.sol[k][P ^ 1];
 #ifdef LMC_EXP_NOGHOST
-      const float solr = dpp_from_right(solb, 0.f);
+      const float solr = row_from_right(solb, 0.f);
 #else
-      const float solr = dpp_from_right(solb, gsolv[k]);
+      const float solr = row_from_right(solb, gsolv[k]);
 #endif
       float cdown = cstep;
       if (EDGE) {
@@ -138,7 +152,7 @@ __device__ __forceinline__ void split_tick_a(const StepArgs& A, const int t, con
       const float sn = fmaf(beta, qn - S.q[k - 1][P], qn);
       if (k == KA) {  // hand the stage over to group B
         float* hb = c.lds + L::o_hand + P * 4 * BWP + kPad + c.col;
-        hb[0] = rn; hb[BWP] = sn; hb[2 * BWP] = pn; hb[3 * BWP] = qn;
+        LW(hb[0], rn); LW(hb[BWP], sn); LW(hb[2 * BWP], pn); LW(hb[3 * BWP], qn);
       } else {
         S.rr[k][P] = rn; S.ss[k][P] = sn; S.p[k][P] = pn; S.q[k][P] = qn;
       }
@@ -147,13 +161,13 @@ __device__ __forceinline__ void split_tick_a(const StepArgs& A, const int t, con
 #endif
     }
 #ifndef LMC_EXP_NOGHOST
-    if (NW > 1) {   // one store per direction: stage values gathered into lanes by DPP, all lanes store
+    {   // one store per direction: the row-edge values of every stage gathered into lanes by DPP, all lanes store
       float gs = 0.f, gq = 0.f;
-      static_for<1, KA + 1>([&](auto kk) { constexpr int k = decltype(kk)::value; gs = gather_lane0<k>(gs, S.sol[k][P]); });
-      c.lds[L::o_gsol + P * L::GB + c.wave * 64 + c.lane] = gs;
+      static_for<1, KA + 1>([&](auto kk) { constexpr int k = decltype(kk)::value; gs = gather_first<k>(gs, S.sol[k][P]); });
+      LW(c.lds[L::o_gsol + P * L::GB + c.wave * 64 + c.lane], gs);
       if constexpr (KA > 1) {
-        static_for<1, KA>([&](auto kk) { constexpr int k = decltype(kk)::value; gq = gather_lane63<k>(gq, S.ss[k][P]); });
-        c.lds[L::o_gss + P * L::GB + (c.wave + 1) * 64 + c.lane] = gq;
+        static_for<1, KA>([&](auto kk) { constexpr int k = decltype(kk)::value; gq = gather_last<k>(gq, S.ss[k][P]); });
+        LW(c.lds[L::o_gss + P * L::GB + (c.wave + 1) * 64 + c.lane], gq);
       }
     }
 #endif
@@ -168,7 +182,7 @@ __device__ __forceinline__ void split_tick_a(const StepArgs& A, const int t, con
     {
       const float* xr = xb + (G::RB - (G::D - 1 - KT)) * BWP + ox;   // x row o1 + KT
 #pragma unroll
-      for (int b = 0; b < KT; ++b) hxn = fmaf(uv[kMaxBlur + b], xr[-b], hxn);
+      for (int b = 0; b < KT; ++b) hxn = fmaf(uv[kMaxBlur + b], LR(xr[-b], S.xpre[1] + (float)b), hxn);
     }
     const int i = o1 + KT - oy;   // residual row
     {
@@ -178,19 +192,19 @@ __device__ __forceinline__ void split_tick_a(const StepArgs& A, const int t, con
 #pragma unroll
       for (int a = KT - 2; a >= 1; --a) S.hxw[a] = S.hxw[a - 1];
       S.hxw[0] = hxn;
-      float rv = acc - S.ypre[P];
+      float rv = acc - S.ypre[U];
       if (EDGE) rv = ((i >= 0) & (i < H)) ? rv : 0.f;
       rv = incol ? rv : 0.f;
-      c.lds[L::o_rrow + P * BWP + kPad + c.col] = rv;
-      int in2 = i + 2;
+      LW(c.lds[L::o_rrow + P * BWP + kPad + c.col], rv);
+      int in2 = i + 4;
       if (EDGE) in2 = in2 < 0 ? 0 : (in2 < H ? in2 : H - 1);
-      S.ypre[P] = LD(A.y, (size_t)in2 * W + c.colc, (size_t)H * W, 2);
+      S.ypre[U] = LD(A.y, (size_t)in2 * W + c.colc, (size_t)H * W, 2);
     }
     float hrn = 0.f;
     {
       const float* rp = c.lds + L::o_rrow + (P ^ 1) * BWP + kPad + c.col - ox;
 #pragma unroll
-      for (int b = 0; b < KT; ++b) hrn = fmaf(uv[kMaxBlur + b], rp[b], hrn);
+      for (int b = 0; b < KT; ++b) hrn = fmaf(uv[kMaxBlur + b], LR(rp[b], S.ypre[1] + (float)b), hrn);
     }
     {
       float acc = uv[KT - 1] * hrn;
@@ -199,10 +213,12 @@ __device__ __forceinline__ void split_tick_a(const StepArgs& A, const int t, con
 #pragma unroll
       for (int a = KT - 2; a >= 1; --a) S.hrw[a] = S.hrw[a - 1];
       S.hrw[0] = hrn;
-      c.lds[L::o_garr + P * BWP + kPad + c.col] = A.sigma_f * acc;
+      LW(c.lds[L::o_garr + P * BWP + kPad + c.col], A.sigma_f * acc);
     }
   }
+#ifndef LMC_EXP_NOBARRIER
   __syncthreads();
+#endif
 }
 
 // ---- group B tick --------------------------------------------------------------------------------------
@@ -221,29 +237,29 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
   if constexpr (K > 0) {
     // stage KA's outputs of the previous tick, and the left neighbour of its ss
     const float* hb = c.lds + L::o_hand + (P ^ 1) * 4 * BWP + kPad + c.col;
-    S.hrr[P ^ 1] = hb[0];
-    S.hss[P ^ 1] = hb[BWP];
-    S.hp[P ^ 1] = hb[2 * BWP];
-    S.hq[P ^ 1] = hb[3 * BWP];
-    const float hssl = hb[BWP - 1];
+    S.hrr[P ^ 1] = LR(hb[0], S.hrr[P] + 1.f);
+    S.hss[P ^ 1] = LR(hb[BWP], S.hss[P] + 1.f);
+    S.hp[P ^ 1] = LR(hb[2 * BWP], S.hp[P] + 1.f);
+    S.hq[P ^ 1] = LR(hb[3 * BWP], S.hq[P] + 1.f);
+    const float hssl = LR(hb[BWP - 1], S.hss[P] + 2.f);
     const float gam = A.tv.gamma, cstep = A.tv.c;
     float gsolv[16], gssv[16];
     if constexpr (K > KA) {
-      load_ghost<(KA + 1) / 4, K / 4>(c.lds + L::o_gsol + (2 + (P ^ 1)) * L::GB + (c.wave + 1) * 64, gsolv);
-      load_ghost<(15 - K) / 4, (15 - (KA + 1)) / 4>(c.lds + L::o_gss + (2 + (P ^ 1)) * L::GB + c.wave * 64 + 48, gssv);
+      load_ghost<(KA + 1) / 4, K / 4>(c.lds + L::o_gsol + (2 + (P ^ 1)) * L::GB + c.wave * 64 + (c.lane & 48) + 16, gsolv);
+      load_ghost<(15 - K) / 4, (15 - (KA + 1)) / 4>(c.lds + L::o_gss + (2 + (P ^ 1)) * L::GB + c.wave * 64 + (c.lane & 48) + 48, gssv);
     }
 #pragma unroll
     for (int k = K + 1; k > KA; --k) {
-      const float xa = xb[(G::RB - (G::E + 2 * k)) * BWP];
+      const float xa = LR(xb[(G::RB - (G::E + 2 * k)) * BWP], S.nz[0] + (float)k);
       float rr1, rr2, ssc, ssl;   // rr^{k-1} on rows a, a-1 ; ss^{k-1} on row a and its left neighbour
       if (k - 1 == KA) {
         rr1 = S.hrr[P ^ 1]; rr2 = S.hrr[P]; ssc = S.hss[P ^ 1]; ssl = hssl;
       } else {
         rr1 = S.rr[k - 1][P ^ 1]; rr2 = S.rr[k - 1][P]; ssc = S.ss[k - 1][P ^ 1];
 #ifdef LMC_EXP_NOGHOST
-        ssl = dpp_from_left(ssc, 0.f);
+        ssl = row_from_left(ssc, 0.f);
 #else
-        ssl = dpp_from_left(ssc, gssv[15 - (k - 1)]);
+        ssl = row_from_left(ssc, gssv[15 - (k - 1)]);
 #endif
       }
       const float sol = fmaf(-gam, (rr1 - rr2) + (ssc - ssl), xa);
@@ -253,9 +269,9 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
       } else {
         const float solb = S.sol[k][P ^ 1];
 #ifdef LMC_EXP_NOGHOST
-        const float solr = dpp_from_right(solb, 0.f);
+        const float solr = row_from_right(solb, 0.f);
 #else
-        const float solr = dpp_from_right(solb, gsolv[k]);
+        const float solr = row_from_right(solb, gsolv[k]);
 #endif
         float cdown = cstep;
         if (EDGE) {
@@ -280,12 +296,12 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
 #endif
     }
 #ifndef LMC_EXP_NOGHOST
-    if constexpr (NW > 1 && K > KA) {
+    if constexpr (K > KA) {
       float gs = 0.f, gq = 0.f;
-      static_for<KA + 1, K + 1>([&](auto kk) { constexpr int k = decltype(kk)::value; gs = gather_lane0<k>(gs, S.sol[k][P]); });
-      c.lds[L::o_gsol + (2 + P) * L::GB + c.wave * 64 + c.lane] = gs;
-      static_for<KA + 1, K + 1>([&](auto kk) { constexpr int k = decltype(kk)::value; gq = gather_lane63<k>(gq, S.ss[k][P]); });
-      c.lds[L::o_gss + (2 + P) * L::GB + (c.wave + 1) * 64 + c.lane] = gq;
+      static_for<KA + 1, K + 1>([&](auto kk) { constexpr int k = decltype(kk)::value; gs = gather_first<k>(gs, S.sol[k][P]); });
+      LW(c.lds[L::o_gsol + (2 + P) * L::GB + c.wave * 64 + c.lane], gs);
+      static_for<KA + 1, K + 1>([&](auto kk) { constexpr int k = decltype(kk)::value; gq = gather_last<k>(gq, S.ss[k][P]); });
+      LW(c.lds[L::o_gss + (2 + P) * L::GB + (c.wave + 1) * 64 + c.lane], gq);
     }
 #endif
   }
@@ -300,10 +316,10 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
 
   if ((!EDGE || (o >= 0 && o < H)) && incol) {
     const size_t gi = (size_t)o * W + c.col;
-    const float x = xb[(G::RB - G::D) * BWP];
+    const float x = LR(xb[(G::RB - G::D) * BWP], S.nz[1] + 3.f);
     float g = 0.f;
     if (A.data_kind == LMC_DATA_BLUR) {
-      g = c.lds[L::o_garr + (P ^ 1) * BWP + kPad + c.col];
+      g = LR(c.lds[L::o_garr + (P ^ 1) * BWP + kPad + c.col], S.nz[2] + 1.f);
     } else if (A.data_kind == LMC_DATA_IDENTITY) {
       g = A.sigma_f * (x - LD(A.y, gi, (size_t)H * W, 3));
     } else if (A.data_kind == LMC_DATA_MASK) {
@@ -325,7 +341,9 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
     if (A.noise_mode == LMC_NOISE_NONE) xi = 0.f;
     ST(c.xout, gi, (size_t)H * W, fmaf(A.a, x, fmaf(-A.t, g, fmaf(A.b, px, A.s * xi))), 7);
   }
+#ifndef LMC_EXP_NOBARRIER
   __syncthreads();
+#endif
 }
 
 template <int K, int NW, int KT>
@@ -367,15 +385,19 @@ __global__ __launch_bounds__(128 * NW) void myula_step_split_kernel(const StepAr
     for (int k = 0; k <= G::KA + 1; ++k) S.sol[k][0] = S.sol[k][1] = 0.f;
 #pragma unroll
     for (int a = 0; a < KT - 1; ++a) S.hxw[a] = S.hrw[a] = 0.f;
-    S.xpre[0] = LD(c.xin, c.colc, img, 8);
-    S.xpre[1] = LD(c.xin, (size_t)(H > 1 ? 1 : 0) * W + c.colc, img, 9);
-    S.ypre[0] = S.ypre[1] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      S.xpre[j] = LD(c.xin, (size_t)(j < H ? j : H - 1) * W + c.colc, img, 8);
+      S.ypre[j] = 0.f;
+    }
     if (A.data_kind == LMC_DATA_BLUR) {
-      // residual row of tick t is i(t) = t - D + 1 + KT - oy; ypre[t & 1] holds y[i(t)] when i(t) is a row
+      // residual row of tick t is i(t) = t - D + 1 + KT - oy; ypre[t & 3] holds y[i(t)] when i(t) is a row
       const int i0 = -G::D + 1 + KT - A.blur.oy;
-      const int r0 = i0 < 0 ? 0 : (i0 < H ? i0 : H - 1), r1 = i0 + 1 < 0 ? 0 : (i0 + 1 < H ? i0 + 1 : H - 1);
-      S.ypre[0] = LD(A.y, (size_t)r0 * W + c.colc, img, 10);
-      S.ypre[1] = LD(A.y, (size_t)r1 * W + c.colc, img, 11);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = i0 + j < 0 ? 0 : (i0 + j < H ? i0 + j : H - 1);
+        S.ypre[j] = LD(A.y, (size_t)r * W + c.colc, img, 10);
+      }
     }
     __syncthreads();
     int tm = 0;

@@ -1,0 +1,9 @@
+#!/bin/bash
+run() { LMC_VARIANT=split timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-moments "$@" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$*', '-> ms/launch', round(d['roofline']['launch_ms'],3))"; }
+run --prior l2
+run --prior l2 --noise none
+run --prior l2 --data identity
+run --prior l2 --data identity --noise none
+run --tv-iters 10 --noise none
+run --tv-iters 10 --data identity
+run --tv-iters 10 --data identity --noise none
