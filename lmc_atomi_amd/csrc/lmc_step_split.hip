@@ -82,7 +82,7 @@ template <int K, int KT>
 struct StateA {
   static constexpr int KA = SplitGeom<K>::KA;
   float rr[KA + 1][2], ss[KA + 1][2], p[KA + 1][2], q[KA + 1][2], sol[KA + 2][2];
-  float hxw[KT - 1], hrw[KT - 1], xpre[4], ypre[4];   // x / y rows in flight: fetched 4 ticks ahead, slot t & 3
+  float hxw[KT > 1 ? KT - 1 : 1], hrw[KT > 1 ? KT - 1 : 1], xpre[4], ypre[4];   // x / y rows in flight: fetched 4 ticks ahead, slot t & 3
 };
 
 template <int K>
@@ -90,6 +90,7 @@ struct StateB {
   float hrr[2], hss[2], hp[2], hq[2];   // stage KA's outputs, two ticks deep (filled from the LDS hand-off)
   float rr[K + 1][2], ss[K + 1][2], p[K + 1][2], q[K + 1][2], sol[K + 2][2];
   float nz[4];
+  float ypre[4], mpre[4];   // y / mask rows of the pointwise data terms, fetched 4 ticks ahead (slot t & 3)
 };
 
 // ---- group A tick --------------------------------------------------------------------------------------
@@ -179,7 +180,7 @@ __device__ __forceinline__ void split_tick_a(const StepArgs& A, const int t, con
   }
 
   // blur gradient pipeline, one row ahead of the output: g[o+1] -> garr[P] (group B reads it next tick)
-  if (A.data_kind == LMC_DATA_BLUR) {
+  if constexpr (KT > 0) {   // KT == 0: pointwise data term, handled by group B
     const int oy = A.blur.oy, ox = A.blur.ox;
     const float* __restrict__ uv = A.blur.h;  // u[0..KT) then v[0..KT) at h[kMaxBlur..], zero padded
     const int o1 = t - G::D + 1;
@@ -227,7 +228,7 @@ __device__ __forceinline__ void split_tick_a(const StepArgs& A, const int t, con
 }
 
 // ---- group B tick --------------------------------------------------------------------------------------
-template <int K, int NW, int U, bool EDGE>
+template <int K, int NW, int KT, int U, bool EDGE>
 __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, const int tm, const SplitCtx& c,
                                              StateB<K>& S) {
   using G = SplitGeom<K>;
@@ -323,13 +324,13 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
     const size_t gi = (size_t)o * W + c.col;
     const float x = LR(xb[(G::RB - G::D) * BWP], S.nz[1] + 3.f);
     float g = 0.f;
-    if (A.data_kind == LMC_DATA_BLUR) {
+    if constexpr (KT > 0) {
       g = LR(c.lds[L::o_garr + (P ^ 1) * BWP + kPad + c.col], S.nz[2] + 1.f);
     } else if (A.data_kind == LMC_DATA_IDENTITY) {
-      g = A.sigma_f * (x - LD(A.y, gi, (size_t)H * W, 3));
+      g = A.sigma_f * (x - S.ypre[U]);
     } else if (A.data_kind == LMC_DATA_MASK) {
-      const float mk = LD(A.mask, gi, (size_t)H * W, 4);
-      g = A.sigma_f * mk * fmaf(mk, x, -LD(A.y, gi, (size_t)H * W, 5));
+      const float mk = S.mpre[U];
+      g = A.sigma_f * mk * fmaf(mk, x, -S.ypre[U]);
     }
     float px;
     if (K > 0) {
@@ -345,6 +346,12 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
     if (A.noise_mode == LMC_NOISE_INJECTED) xi = LD(A.noise, (size_t)c.chain * H * W + gi, (size_t)A.C * H * W, 6);
     if (A.noise_mode == LMC_NOISE_NONE) xi = 0.f;
     ST(c.xout, gi, (size_t)H * W, fmaf(A.a, x, fmaf(-A.t, g, fmaf(A.b, px, A.s * xi))), 7);
+  }
+  if (KT == 0 && (A.data_kind == LMC_DATA_IDENTITY || A.data_kind == LMC_DATA_MASK)) {   // rows o+4 of y (and mask) for tick t+4
+    int on = o + 4;
+    on = on < 0 ? 0 : (on < H ? on : H - 1);
+    S.ypre[U] = LD(A.y, (size_t)on * W + c.colc, (size_t)H * W, 3);
+    if (A.data_kind == LMC_DATA_MASK) S.mpre[U] = LD(A.mask, (size_t)on * W + c.colc, (size_t)H * W, 4);
   }
 #ifndef LMC_EXP_NOBARRIER
   __syncthreads();
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(128 * NW) void myula_step_split_kernel(const StepAr
       S.xpre[j] = LD(c.xin, (size_t)(j < H ? j : H - 1) * W + c.colc, img, 8);
       S.ypre[j] = 0.f;
     }
-    if (A.data_kind == LMC_DATA_BLUR) {
+    if constexpr (KT > 0) {
       // residual row of tick t is i(t) = t - D + 1 + KT - oy; ypre[t & 3] holds y[i(t)] when i(t) is a row
       const int i0 = -G::D + 1 + KT - A.blur.oy;
 #pragma unroll
@@ -438,6 +445,20 @@ __global__ __launch_bounds__(128 * NW) void myula_step_split_kernel(const StepAr
 #pragma unroll
     for (int k = 0; k <= K + 1; ++k) S.sol[k][0] = S.sol[k][1] = 0.f;
     S.nz[0] = S.nz[1] = S.nz[2] = S.nz[3] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // output row of tick j is j - D (< 0): slots are refilled before they are used
+      S.ypre[j] = 0.f;
+      S.mpre[j] = 0.f;
+    }
+    if (KT == 0 && (A.data_kind == LMC_DATA_IDENTITY || A.data_kind == LMC_DATA_MASK)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int o0 = j - G::D;
+        o0 = o0 < 0 ? 0 : (o0 < H ? o0 : H - 1);
+        S.ypre[j] = LD(A.y, (size_t)o0 * W + c.colc, img, 3);
+        if (A.data_kind == LMC_DATA_MASK) S.mpre[j] = LD(A.mask, (size_t)o0 * W + c.colc, img, 4);
+      }
+    }
     __syncthreads();
     int tm = 0;
     for (int t0 = 0; t0 < T; t0 += 4) {
@@ -447,15 +468,15 @@ __global__ __launch_bounds__(128 * NW) void myula_step_split_kernel(const StepAr
       const bool steady = (t0 >= t_lo) && (t0 + 3 + 2 < H);
 #endif
       if (steady) {
-        split_tick_b<K, NW, 0, false>(A, t0 + 0, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_b<K, NW, 1, false>(A, t0 + 1, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_b<K, NW, 2, false>(A, t0 + 2, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_b<K, NW, 3, false>(A, t0 + 3, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
+        split_tick_b<K, NW, KT, 0, false>(A, t0 + 0, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
+        split_tick_b<K, NW, KT, 1, false>(A, t0 + 1, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
+        split_tick_b<K, NW, KT, 2, false>(A, t0 + 2, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
+        split_tick_b<K, NW, KT, 3, false>(A, t0 + 3, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
       } else {
-        split_tick_b<K, NW, 0, true>(A, t0 + 0, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_b<K, NW, 1, true>(A, t0 + 1, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_b<K, NW, 2, true>(A, t0 + 2, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_b<K, NW, 3, true>(A, t0 + 3, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
+        split_tick_b<K, NW, KT, 0, true>(A, t0 + 0, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
+        split_tick_b<K, NW, KT, 1, true>(A, t0 + 1, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
+        split_tick_b<K, NW, KT, 2, true>(A, t0 + 2, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
+        split_tick_b<K, NW, KT, 3, true>(A, t0 + 3, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
       }
     }
   }
@@ -501,6 +522,7 @@ static hipError_t launch_split_k(const StepArgs& a, hipStream_t st) {
 
 template <int K>
 static hipError_t launch_split_kt(const StepArgs& a, int KT, hipStream_t st) {
+  if (KT == 0) return launch_split_k<K, 0>(a, st);   // no blur: pointwise (identity / mask / none) data term
   if (KT <= 5) return launch_split_k<K, 5>(a, st);
   return launch_split_k<K, 7>(a, st);
 }
@@ -538,7 +560,7 @@ bool split_supported(const StepArgs& a) {
 }
 
 hipError_t launch_step_split(StepArgs a, hipStream_t st) {
-  int KT = 5;
+  int KT = 0;
   if (a.data_kind == LMC_DATA_BLUR) {
     float u[kMaxBlur] = {0}, v[kMaxBlur] = {0};
     if (!separate_blur_taps(a.blur, u, v)) return hipErrorInvalidConfiguration;
