@@ -52,7 +52,9 @@ typedef enum lmc_prior_kind {
   LMC_PRIOR_NONE = 0,   /* prox = identity */
   LMC_PRIOR_L2 = 1,     /* g = sigma/2 ||x||^2      : prox_t = x / (1 + t*sigma)          */
   LMC_PRIOR_L1 = 2,     /* g = sigma ||x||_1        : soft threshold t*sigma  (prox.py:18) */
-  LMC_PRIOR_TV_ISO = 3  /* g = sigma TV_iso(x)      : tv_niter FGP dual iterations (pyproximal.TV, prox_lmc_deconv.py:122) */
+  LMC_PRIOR_TV_ISO = 3, /* g = sigma TV_iso(x)      : tv_niter FGP dual iterations (pyproximal.TV, prox_lmc_deconv.py:122);
+                         *  in ULPDA: g o A with g = sigma*L21 (prox_lmc_deconv.py:116), dual prox = l2-ball projection */
+  LMC_PRIOR_TV_ANISO = 4 /* ULPDA / energies only: g o A with g = sigma*L1 (prox_lmc_deconv.py:119), dual prox = clip */
 } lmc_prior_kind;
 
 typedef enum lmc_noise_mode {
@@ -107,6 +109,15 @@ int lmc_gradient_adjoint(const float* y_dev, float* out_dev, int64_t n_img, int3
  * `pt` is the prox parameter (epsg*gamma in MYULA). */
 int lmc_fused_eval(const lmc_problem* prob, const float* x_dev, float* out_dev, int64_t n_img,
                    float a, float t, float b, float pt, void* stream);
+
+/* Implicit data step  out = prox_{tau f}(x) = (I + tau*sigma_f*Op^T Op)^{-1} (x + tau*sigma_f*Op^T y)  for n_img images:
+ * pyproximal.L2.prox / algs.py:224-256 (row a8).  LMC_DATA_BLUR: `niter` conjugate-gradient iterations started from
+ * `out` as given if warm != 0, else from zero (the reference: LSQR, niter=50, warm start; build-specified solver).
+ * IDENTITY / MASK / NONE: closed form.  workspace_dev: 5*n_img*H*W floats followed (8-byte aligned) by 3*n_img doubles;
+ * lmc_l2_prox_workspace_bytes gives the size. */
+size_t lmc_l2_prox_workspace_bytes(int64_t n_img, int32_t H, int32_t W);
+int lmc_l2_prox(const lmc_problem* prob, const float* x_dev, float* out_dev, int64_t n_img, float tau, int32_t niter,
+                int32_t warm, void* workspace_dev, void* stream);
 
 /* f_out[i] = f(x_i), g_out[i] = g(x_i) (double, device, n_img each; either may be NULL).
  * Replaces proxf(x), proxg(x) of the energy log (algs.py:461-466, 578-582). */
@@ -186,6 +197,36 @@ int lmc_sampler_enable_timing(lmc_sampler* s, int32_t on);
 int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_launches);
 /* name of the step kernel variant selected for this configuration (for profiles/) */
 const char* lmc_sampler_kernel_name(const lmc_sampler* s);
+
+/* ---- ULPDA sampler (replaces algs.UnadjustedLangevinPrimalDual, algs.py:295-474) --------------------
+ *   x    <- prox_{tau f}(x - tau (A^T y + z)) + sqrt(2 tau) xi      (algs.py:440/446)
+ *   xhat <- x + theta (x - x_old)                                   (:441/447)
+ *   y    <- prox_{mu g*}(y + mu A xhat)                             (:436/448)   order set by gfirst (:435)
+ * A = forward-difference gradient (prox_lmc_deconv.py:98); g = problem.prior (TV_ISO -> L21, TV_ANISO -> L1);
+ * f = problem data term; for LMC_DATA_BLUR the implicit step (I + tau*sigma_f*H^T H)^{-1} is `cg_niter`
+ * warm-started conjugate-gradient iterations per chain (the reference: <= 50 LSQR iterations, algs.py:247-256).
+ * The handle is an lmc_sampler: set_state / get_state / step / energies / moments / noise / destroy apply. */
+typedef struct lmc_ulpda_config {
+  uint32_t struct_size;     /* = sizeof(lmc_ulpda_config) */
+  lmc_problem problem;
+  int32_t n_chains;
+  int64_t chain_offset;
+  float tau, mu, theta;     /* algs.py:295-296 (scalars; per-iteration arrays: lmc_sampler_set_steps between calls) */
+  int32_t gfirst;           /* algs.py:296, 435 */
+  int32_t cg_niter;         /* inner iterations of the implicit data step (niter=50 at prox_lmc_deconv.py:101) */
+  int32_t warm;             /* warm-start the inner solver from the previous solve (warm=True at :101) */
+  const float* z_dev;       /* optional additional vector z [H][W] (algs.py:438-439), NULL = none */
+  uint64_t seed;
+  int32_t noise_mode;
+  int32_t moments, burn_in, thin;
+} lmc_ulpda_config;
+
+int lmc_ulpda_create(const lmc_ulpda_config* cfg, lmc_sampler** out);
+/* dual variable y [n_chains][2][H][W] (y0 of algs.py:427; y_samples of :451) */
+int lmc_sampler_set_dual(lmc_sampler* s, const float* y_dev, void* stream);
+int lmc_sampler_get_dual(lmc_sampler* s, float* y_dev, void* stream);
+/* change (tau, mu) for the following iterations (the reference accepts per-iteration arrays, algs.py:402-408) */
+int lmc_sampler_set_steps(lmc_sampler* s, float tau, float mu);
 
 /* Step-kernel variant used by lmc_sampler_step / lmc_fused_eval: 0 = auto (default), 1 = LDS-tiled,
  * 2 = streaming register pipeline (one wave group), 3 = the same pipeline split over two wave groups.  Returns the previous setting (>= 0) or a negative lmc_status.

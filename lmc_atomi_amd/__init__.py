@@ -6,7 +6,8 @@ from . import _capi
 from ._capi import LMCError
 from .operators import Convolve2D, Diagonal, Gradient, Identity, LinearOperator
 from .proximal import L1, L2, L21, TV, ProxOperator, fgp_betas
-from .algs import (MYULAResult, MYULASampler, MoreauYosidaUnadjustedLangevin, mean_var_from_moments,
+from .algs import (MYULAResult, MYULASampler, MoreauYosidaUnadjustedLangevin, ULPDASampler,
+                   UnadjustedLangevinPrimalDual, mean_var_from_moments,
                    set_step_variant)
 
 from .sharding import allreduce_moments, chain_shard, posterior_mean_var, sharded_myula
@@ -15,6 +16,6 @@ __all__ = [
     "allreduce_moments", "chain_shard", "posterior_mean_var", "sharded_myula",
     "LMCError", "Convolve2D", "Diagonal", "Gradient", "Identity", "LinearOperator",
     "L1", "L2", "L21", "TV", "ProxOperator", "fgp_betas",
-    "MYULASampler", "MYULAResult", "MoreauYosidaUnadjustedLangevin", "mean_var_from_moments", "set_step_variant",
+    "MYULASampler", "MYULAResult", "MoreauYosidaUnadjustedLangevin", "ULPDASampler", "UnadjustedLangevinPrimalDual", "mean_var_from_moments", "set_step_variant",
 ]
 __version__ = "0.1.0"

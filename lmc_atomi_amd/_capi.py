@@ -15,7 +15,7 @@ ABI_VERSION = 1
 
 # enums (include/lmc_atomi.h)
 DATA_NONE, DATA_IDENTITY, DATA_BLUR, DATA_MASK = 0, 1, 2, 3
-PRIOR_NONE, PRIOR_L2, PRIOR_L1, PRIOR_TV_ISO = 0, 1, 2, 3
+PRIOR_NONE, PRIOR_L2, PRIOR_L1, PRIOR_TV_ISO, PRIOR_TV_ANISO = 0, 1, 2, 3, 4
 NOISE_PHILOX, NOISE_INJECTED, NOISE_NONE = 0, 1, 2
 MAX_BLUR = 9
 MAX_TV_ITERS = 64
@@ -65,6 +65,23 @@ class lmc_myula_config(C.Structure):
     ]
 
 
+class lmc_ulpda_config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("problem", lmc_problem),
+        ("n_chains", C.c_int32),
+        ("chain_offset", C.c_int64),
+        ("tau", C.c_float), ("mu", C.c_float), ("theta", C.c_float),
+        ("gfirst", C.c_int32),
+        ("cg_niter", C.c_int32),
+        ("warm", C.c_int32),
+        ("z_dev", C.c_void_p),
+        ("seed", C.c_uint64),
+        ("noise_mode", C.c_int32),
+        ("moments", C.c_int32), ("burn_in", C.c_int32), ("thin", C.c_int32),
+    ]
+
+
 _P = C.c_void_p
 _F = C.POINTER(C.c_float)
 _SIGNATURES = {
@@ -75,6 +92,8 @@ _SIGNATURES = {
     "lmc_gradient": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "lmc_gradient_adjoint": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "lmc_fused_eval": (C.c_int, [C.POINTER(lmc_problem), _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "lmc_l2_prox_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "lmc_l2_prox": (C.c_int, [C.POINTER(lmc_problem), _P, _P, C.c_int64, C.c_float, C.c_int32, C.c_int32, _P, _P]),
     "lmc_energies": (C.c_int, [C.POINTER(lmc_problem), _P, C.c_int64, _P, _P, _P]),
     "lmc_dual_project": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
     "lmc_prox_elementwise": (C.c_int, [C.c_int32, _P, _P, C.c_int64, _F, C.c_int32, _P]),
@@ -93,6 +112,10 @@ _SIGNATURES = {
     "lmc_sampler_last_step_timing": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "lmc_sampler_kernel_name": (C.c_char_p, [_P]),
     "lmc_set_step_variant": (C.c_int, [C.c_int32]),
+    "lmc_ulpda_create": (C.c_int, [C.POINTER(lmc_ulpda_config), C.POINTER(_P)]),
+    "lmc_sampler_set_dual": (C.c_int, [_P, _P, _P]),
+    "lmc_sampler_get_dual": (C.c_int, [_P, _P, _P]),
+    "lmc_sampler_set_steps": (C.c_int, [_P, C.c_float, C.c_float]),
 }
 
 _lib = None

@@ -171,6 +171,148 @@ class MYULASampler:
         _capi.check(_dev.lib().lmc_sampler_reset_moments(self._h, _dev.stream_ptr()))
 
 
+class ULPDASampler(MYULASampler):
+    """Many-chain ULPDA on one GPU (algs.py:425-449).  ``proxf`` = data term (L2 with Convolve2D / Diagonal / Identity /
+    no operator), ``proxg`` = L21 (isotropic) or L1 (anisotropic) acting on ``A x`` with ``A`` the forward-difference
+    gradient.  The implicit data step runs ``proxf.niter`` warm-started CG iterations per chain on the GPU."""
+
+    def __init__(self, proxf, proxg, A, dims, n_chains=1, tau=None, mu=None, theta=1.0, gfirst=True, z=None, seed=0,
+                 chain_offset=0, noise="philox", moments=False, burn_in=0, thin=1, device=None):
+        from .operators import Gradient
+        from .proximal import L1, L21
+        if not isinstance(A, Gradient):
+            raise NotImplementedError("ULPDA on the GPU supports A = Gradient (the reference's operator, prox_lmc_deconv.py:98)")
+        if isinstance(proxg, L21):
+            prior = {"prior_kind": _capi.PRIOR_TV_ISO, "prior_sigma": proxg.sigma, "tv_niter": 1, "tv_betas": [0.0]}
+        elif isinstance(proxg, L1):
+            prior = {"prior_kind": _capi.PRIOR_TV_ANISO, "prior_sigma": proxg.sigma}
+        else:
+            raise NotImplementedError(f"{type(proxg).__name__} has no dual-prox device functor (L21 or L1 expected)")
+        self.dims = (int(dims[0]), int(dims[1]))
+        self.n_chains = int(n_chains)
+        self.device = _dev.device(device)
+        self.proxf, self.proxg = proxf, proxg
+        self._problem = _Problem(self.dims, _data_descriptor(proxf), prior, self.device)
+        cfg = _capi.lmc_ulpda_config()
+        cfg.struct_size = C.sizeof(_capi.lmc_ulpda_config)
+        cfg.problem = self._problem.c
+        cfg.n_chains = self.n_chains
+        cfg.chain_offset = int(chain_offset)
+        cfg.tau, cfg.mu, cfg.theta = float(tau), float(mu), float(theta)
+        cfg.gfirst = 1 if gfirst else 0
+        cfg.cg_niter = int(getattr(proxf, "niter", 10) or 10)
+        cfg.warm = 1 if getattr(proxf, "warm", True) else 0
+        self._z = None
+        if z is not None:
+            self._z = _dev.to_dev(z, self.device).reshape(self.dims)
+            cfg.z_dev = self._z.data_ptr()
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.noise_mode = {"philox": _capi.NOISE_PHILOX, "injected": _capi.NOISE_INJECTED, "none": _capi.NOISE_NONE}[noise]
+        cfg.moments = 1 if moments else 0
+        cfg.burn_in = int(burn_in)
+        cfg.thin = int(thin)
+        self.noise_mode = noise
+        self.moments_on = bool(moments)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _capi.check(_dev.lib().lmc_ulpda_create(C.byref(cfg), C.byref(self._h)))
+
+    def set_steps(self, tau, mu):
+        _capi.check(_dev.lib().lmc_sampler_set_steps(self._h, float(tau), float(mu)))
+
+    def set_dual(self, y):
+        yt = _dev.to_dev(y, self.device)
+        n2 = 2 * self.dims[0] * self.dims[1]
+        if yt.numel() == n2:
+            yt = yt.reshape(1, n2).expand(self.n_chains, n2).contiguous()
+        if yt.numel() != self.n_chains * n2:
+            raise ValueError("dual state must have 2*H*W entries per chain")
+        _capi.check(_dev.lib().lmc_sampler_set_dual(self._h, _dev.ptr(yt), _dev.stream_ptr()))
+        torch.cuda.current_stream().synchronize()
+
+    def get_dual(self):
+        out = torch.empty((self.n_chains, 2) + self.dims, dtype=torch.float32, device=self.device)
+        _capi.check(_dev.lib().lmc_sampler_get_dual(self._h, _dev.ptr(out), _dev.stream_ptr()))
+        return out
+
+
+def UnadjustedLangevinPrimalDual(proxf, proxg, A, x0, tau, mu, y0=None, z=None, theta=1., niter=10, seed=0, gfirst=True,
+                                 callback=None, callbacky=False, returny=False, show=False, *, n_chains=None, dims=None,
+                                 rng="philox", chain_offset=0, burn_in=0, thin=1, device=None):
+    r"""Unadjusted Langevin Primal-Dual algorithm (ULPDA) -- drop-in for algs.py:295-474.
+
+    Reference form (``n_chains is None``): one chain, returns ``np.ndarray (niter, n)`` (and the duals ``(niter, 2n)`` with
+    ``returny``), ``callback(x)`` / ``callback(x, y)`` every iteration, ``tau`` / ``mu`` scalars or per-iteration arrays
+    (algs.py:402-408).  ``rng='pcg64'`` injects the reference's noise stream.  Many-chain form: :class:`MYULAResult`.
+    """
+    if dims is None:
+        dims = getattr(A, "dims", None) or getattr(proxf, "dims", None)
+    if dims is None:
+        raise ValueError("image shape unknown: pass dims=(ny, nx)")
+    many = n_chains is not None
+    C_ = int(n_chains) if many else 1
+    n = int(dims[0]) * int(dims[1])
+    if rng not in ("philox", "pcg64"):
+        raise ValueError("rng must be 'philox' or 'pcg64'")
+    if rng == "pcg64" and C_ != 1:
+        raise ValueError("rng='pcg64' reproduces the reference's single chain; use n_chains=None")
+    taus = np.full(niter, tau, dtype=np.float64) if np.isscalar(tau) else np.asarray(tau, dtype=np.float64)
+    mus = np.full(niter, mu, dtype=np.float64) if np.isscalar(mu) else np.asarray(mu, dtype=np.float64)
+    smp = ULPDASampler(proxf, proxg, A, dims, n_chains=C_, tau=taus[0], mu=mus[0], theta=theta, gfirst=gfirst, z=z,
+                       seed=seed, chain_offset=chain_offset, noise="injected" if rng == "pcg64" else "philox",
+                       moments=many, burn_in=burn_in, thin=thin, device=device)
+    try:
+        smp.set_state(x0)
+        if y0 is not None:
+            smp.set_dual(y0)
+        tstart = time.time()
+        if show:
+            print('Unadjusted Langevin primal-dual (lmc_atomi_amd / HIP): U(x) = f(x) + x^T z + g(Ax)\n'
+                  '---------------------------------------------------------\n'
+                  'Proximal operator (f): %s\nProximal operator (g): %s\nLinear operator (A): %s\n'
+                  'tau = %s\t\tmu = %s\ntheta = %.2f\t\tniter = %d\tchains = %d\n' %
+                  (type(proxf), type(proxg), type(A), str(taus[0]), str(mus[0]), theta, niter, C_))
+            print('   Itn       x[0]          f         g o A      U = f + g o A')
+        host_rng = default_rng(seed) if rng == "pcg64" else None
+        xs = np.empty((niter, n), dtype=np.float64) if not many else None
+        ys = np.empty((niter, 2 * n), dtype=np.float64) if (returny and not many) else None
+        for it in range(niter):
+            smp.set_steps(taus[it], mus[it])
+            if host_rng is not None:
+                xi = host_rng.standard_normal(n)                        # algs.py:433
+                smp.step(1, noise=xi.reshape(1, 1, *smp.dims))
+            else:
+                smp.step(1)
+            if not many:
+                xs[it] = smp.get_state().reshape(-1).cpu().numpy()
+                if returny or callbacky:
+                    yk = smp.get_dual().reshape(-1).cpu().numpy()
+                    if returny:
+                        ys[it] = yk
+                if callback is not None:
+                    callback(xs[it], yk) if callbacky else callback(xs[it])
+            elif callback is not None:
+                callback(smp.get_state(), smp.get_dual()) if callbacky else callback(smp.get_state())
+            if show and (it < 10 or niter - it < 10 or it % max(niter // 10, 1) == 0):
+                f, g = smp.energies()
+                x00 = float(smp.get_state().reshape(-1)[0])
+                print('%6g  %12.5e  %10.3e  %10.3e      %10.3e' % (it + 1, x00, float(f.mean()), float(g.mean()),
+                                                                  float((f + g).mean())))
+        if show:
+            print('\nTotal time (s) = %.2f' % (time.time() - tstart))
+            print('---------------------------------------------------------\n')
+        if not many:
+            return (xs, ys) if returny else xs
+        s1, s2, cnt = smp.moments()
+        f, g = smp.energies()
+        state = smp.get_state()
+        torch.cuda.current_stream().synchronize()
+        mean, var = mean_var_from_moments(s1, s2, max(cnt, 1))
+        return MYULAResult(state, mean, var, cnt, f, g, time.time() - tstart)
+    finally:
+        smp.close()
+
+
 def mean_var_from_moments(s1, s2, count):
     """Posterior mean and pixel-wise variance from accumulated sums (any array type)."""
     mean = s1 / count

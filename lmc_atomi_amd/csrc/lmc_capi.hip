@@ -97,7 +97,7 @@ int load_problem(const lmc_problem* p, Problem& q) {
   q.prior_kind = p->prior_kind;
   q.prior_sigma = p->prior_sigma;
   switch (p->prior_kind) {
-    case LMC_PRIOR_NONE: case LMC_PRIOR_L2: case LMC_PRIOR_L1: break;
+    case LMC_PRIOR_NONE: case LMC_PRIOR_L2: case LMC_PRIOR_L1: case LMC_PRIOR_TV_ANISO: break;
     case LMC_PRIOR_TV_ISO:
       if (p->tv_niter < 1 || p->tv_niter > lmc::kMaxTvIters)
         return fail(LMC_E_UNSUPPORTED, "tv_niter %d outside 1..%d", p->tv_niter, lmc::kMaxTvIters);
@@ -168,6 +168,14 @@ hipError_t launch_step(const lmc::StepArgs& A, hipStream_t st, const char** name
 }  // namespace
 
 struct lmc_sampler {
+  int kind = 0;   // 0 MYULA, 1 ULPDA
+  // ULPDA state (kind == 1)
+  float mu = 0, theta = 1;
+  int gfirst = 0, cg_niter = 0, warm = 1;
+  const float* z = nullptr;
+  float* xhat = nullptr; float* ydual = nullptr; float* uw = nullptr; float* rhs = nullptr;
+  float* cr = nullptr; float* cp = nullptr; float* cq = nullptr; float* ctmp = nullptr; float* xi = nullptr;
+  float* htb = nullptr; double* scal = nullptr;
   Problem prob;
   int C = 0;
   int64_t chain_offset = 0;
@@ -270,6 +278,41 @@ int lmc_energies(const lmc_problem* prob, const float* x_dev, int64_t n_img, dou
   return LMC_OK;
 }
 
+size_t lmc_l2_prox_workspace_bytes(int64_t n_img, int32_t H, int32_t W) {
+  const size_t n = (size_t)n_img * H * W;
+  return ((5 * n * sizeof(float) + 7) / 8) * 8 + 3 * (size_t)n_img * sizeof(double);
+}
+
+int lmc_l2_prox(const lmc_problem* prob, const float* x_dev, float* out_dev, int64_t n_img, float tau, int32_t niter,
+                int32_t warm, void* workspace_dev, void* stream) {
+  Problem q;
+  int rc = load_problem(prob, q);
+  if (rc) return rc;
+  if (!x_dev || !out_dev || x_dev == out_dev || n_img < 1) return fail(LMC_E_INVALID, "bad arguments (in-place not allowed)");
+  if (!(tau > 0.f)) return fail(LMC_E_INVALID, "tau must be > 0");
+  hipStream_t st = S(stream);
+  const float ts = tau * q.sigma_f;
+  const size_t n = (size_t)n_img * q.H * q.W;
+  if (q.data_kind != LMC_DATA_BLUR) {
+    HIP_TRY(lmc::ulpda_pointwise_prox(x_dev, out_dev, q.y, q.mask, n_img, q.H, q.W, ts, q.data_kind, st));
+    return LMC_OK;
+  }
+  if (niter < 1) return fail(LMC_E_INVALID, "niter must be >= 1");
+  if (!workspace_dev) return fail(LMC_E_INVALID, "workspace_dev is NULL (see lmc_l2_prox_workspace_bytes)");
+  float* w = static_cast<float*>(workspace_dev);
+  float *rhs = w, *r = w + n, *p = w + 2 * n, *qq = w + 3 * n, *tmp = w + 4 * n;
+  double* scal = reinterpret_cast<double*>(static_cast<char*>(workspace_dev) + ((5 * n * sizeof(float) + 7) / 8) * 8);
+  // rhs = x + ts * H^T y  : H^T y into tmp (one image), then broadcast-add through the rhs kernel with y == 0
+  HIP_TRY(lmc::launch_blur(q.y, tmp, 1, q.H, q.W, q.taps, 1, st));
+  // ulpda_rhs computes x - tau*(A^T ydual) + ts*htb; with a zero dual field it is x + ts*htb.  The dual field needs 2n
+  // floats: use r and p (both overwritten later by the solver) as a zeroed [n_img][2][H][W] field.
+  HIP_TRY(hipMemsetAsync(r, 0, sizeof(float) * 2 * n, st));
+  HIP_TRY(lmc::ulpda_rhs(x_dev, r, nullptr, tmp, rhs, n_img, q.H, q.W, 0.f, ts, st));
+  if (!warm) HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(float) * n, st));
+  HIP_TRY(lmc::ulpda_cg_solve(out_dev, rhs, r, p, qq, tmp, scal, n_img, q.H, q.W, q.taps, ts, niter, st));
+  return LMC_OK;
+}
+
 int lmc_dual_project(const float* y_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W, float radius,
                      int32_t isotropic, void* stream) {
   if (!y_dev || !out_dev) return fail(LMC_E_INVALID, "NULL pointer");
@@ -345,6 +388,9 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
 
 void lmc_sampler_destroy(lmc_sampler* s) {
   if (!s) return;
+  for (float* b : {s->xhat, s->ydual, s->uw, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb})
+    if (b) (void)hipFree(b);
+  if (s->scal) (void)hipFree(s->scal);
   if (s->x[0]) (void)hipFree(s->x[0]);
   if (s->x[1]) (void)hipFree(s->x[1]);
   if (s->s1) (void)hipFree(s->s1);
@@ -357,6 +403,7 @@ int lmc_sampler_set_state(lmc_sampler* s, const float* x_dev, void* stream) {
   if (!s || !x_dev) return fail(LMC_E_INVALID, "NULL argument");
   const size_t nbytes = sizeof(float) * (size_t)s->C * s->prob.H * s->prob.W;
   HIP_TRY(hipMemcpyAsync(s->x[s->cur], x_dev, nbytes, hipMemcpyDeviceToDevice, S(stream)));
+  if (s->kind == 1) HIP_TRY(hipMemcpyAsync(s->xhat, x_dev, nbytes, hipMemcpyDeviceToDevice, S(stream)));   // xhat = x (algs.py:426)
   return LMC_OK;
 }
 
@@ -367,8 +414,18 @@ int lmc_sampler_get_state(lmc_sampler* s, float* x_dev, void* stream) {
   return LMC_OK;
 }
 
+static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, hipStream_t st);
+
 int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, void* stream) {
   if (!s) return fail(LMC_E_INVALID, "NULL sampler");
+  if (s->kind == 1) {
+    if (n_iters < 0) return fail(LMC_E_INVALID, "n_iters < 0");
+    if (s->noise_mode == LMC_NOISE_INJECTED && !noise_dev && n_iters > 0)
+      return fail(LMC_E_INVALID, "noise_mode is INJECTED but noise_dev is NULL");
+    if (s->noise_mode != LMC_NOISE_INJECTED && noise_dev)
+      return fail(LMC_E_INVALID, "noise_dev given but noise_mode is not INJECTED");
+    return ulpda_step(s, n_iters, noise_dev, S(stream));
+  }
   if (n_iters < 0) return fail(LMC_E_INVALID, "n_iters < 0");
   if (s->noise_mode == LMC_NOISE_INJECTED && !noise_dev && n_iters > 0)
     return fail(LMC_E_INVALID, "noise_mode is INJECTED but noise_dev is NULL");
@@ -417,6 +474,134 @@ int lmc_sampler_enable_timing(lmc_sampler* s, int32_t on) {
   if (!s) return fail(LMC_E_INVALID, "NULL sampler");
   s->timing = on != 0;
   s->timed = false;
+  return LMC_OK;
+}
+
+// ---- ULPDA ---------------------------------------------------------------------------------------
+
+static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, hipStream_t st) {
+  const int H = s->prob.H, W = s->prob.W;
+  const int64_t C = s->C;
+  const size_t per_iter = (size_t)C * H * W;
+  const int iso = s->prob.prior_kind == LMC_PRIOR_TV_ISO;
+  float* x = s->x[s->cur];
+  s->timed = false;
+  s->last_launches = 0;
+  if (s->iteration + n_iters > 0xFFFFFFFFLL) return fail(LMC_E_STATE, "iteration counter would exceed 32 bits");
+  for (int k = 0; k < n_iters; ++k) {
+    const float ts = s->tau * s->prob.sigma_f;
+    if (s->gfirst)   // y <- proxdual(y + mu A xhat)   (algs.py:436)
+      HIP_TRY(lmc::ulpda_dual_update(s->xhat, s->ydual, C, H, W, s->mu, s->prob.prior_sigma, iso, st));
+    // v = x - tau (A^T y + z) [+ tau sigma H^T b]      (algs.py:437-440 / 443-446)
+    HIP_TRY(lmc::ulpda_rhs(x, s->ydual, s->z, s->prob.data_kind == LMC_DATA_BLUR ? s->htb : nullptr, s->rhs, C, H, W, s->tau, ts, st));
+    const float* u = s->rhs;
+    if (s->prob.data_kind == LMC_DATA_BLUR) {
+      if (!s->warm) HIP_TRY(hipMemsetAsync(s->uw, 0, sizeof(float) * per_iter, st));
+      HIP_TRY(lmc::ulpda_cg_solve(s->uw, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->scal, C, H, W, s->prob.taps, ts, s->cg_niter, st));
+      u = s->uw;
+    } else if (s->prob.data_kind != LMC_DATA_NONE) {
+      HIP_TRY(lmc::ulpda_pointwise_prox(s->rhs, s->uw, s->prob.y, s->prob.mask, C, H, W, ts, s->prob.data_kind, st));
+      u = s->uw;
+    }
+    const float* xi = nullptr;
+    if (s->noise_mode == LMC_NOISE_INJECTED) xi = noise_dev + (size_t)k * per_iter;
+    else if (s->noise_mode == LMC_NOISE_PHILOX) {
+      HIP_TRY(lmc::launch_noise(s->xi, (int)C, H, W, s->base.key0, s->base.key1, (uint32_t)s->iteration, s->base.chain_offset, st));
+      xi = s->xi;
+    }
+    // x <- u + sqrt(2 tau) xi ; xhat <- x + theta (x - x_old)     (algs.py:440-441 / 446-447)
+    HIP_TRY(lmc::ulpda_finish(x, s->xhat, u, xi, C, H, W, std::sqrt(2.f * s->tau), s->theta, st));
+    if (!s->gfirst)  // (algs.py:448)
+      HIP_TRY(lmc::ulpda_dual_update(s->xhat, s->ydual, C, H, W, s->mu, s->prob.prior_sigma, iso, st));
+    if (s->moments && s->iteration >= s->burn_in && (s->iteration - s->burn_in) % s->thin == 0) {
+      HIP_TRY(lmc::launch_moments(x, s->C, H, W, s->s1, s->s2, st));
+      s->count += (uint64_t)s->C;
+    }
+    ++s->iteration;
+  }
+  s->kernel_name = "ulpda (multi-kernel)";
+  return LMC_OK;
+}
+
+int lmc_ulpda_create(const lmc_ulpda_config* cfg, lmc_sampler** out) {
+  if (!cfg || !out) return fail(LMC_E_INVALID, "NULL argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(lmc_ulpda_config))
+    return fail(LMC_E_INVALID, "lmc_ulpda_config.struct_size %u != %zu (ABI mismatch)", cfg->struct_size, sizeof(lmc_ulpda_config));
+  if (cfg->n_chains < 1) return fail(LMC_E_INVALID, "n_chains must be >= 1");
+  if (cfg->chain_offset < 0 || cfg->chain_offset + cfg->n_chains > 0xFFFFFFFFLL)
+    return fail(LMC_E_INVALID, "global chain ids must fit 32 bits");
+  if (!(cfg->tau > 0.f) || !(cfg->mu > 0.f)) return fail(LMC_E_INVALID, "tau and mu must be > 0");
+  if (cfg->noise_mode < LMC_NOISE_PHILOX || cfg->noise_mode > LMC_NOISE_NONE) return fail(LMC_E_INVALID, "bad noise_mode");
+  if (cfg->problem.prior_kind != LMC_PRIOR_TV_ISO && cfg->problem.prior_kind != LMC_PRIOR_TV_ANISO)
+    return fail(LMC_E_UNSUPPORTED, "ULPDA needs g o A with g = L21 (LMC_PRIOR_TV_ISO) or L1 (LMC_PRIOR_TV_ANISO)");
+  if (!(cfg->problem.prior_sigma > 0.f)) return fail(LMC_E_INVALID, "prior_sigma (dual ball radius) must be > 0");
+  if (cfg->problem.data_kind == LMC_DATA_BLUR && cfg->cg_niter < 1) return fail(LMC_E_INVALID, "cg_niter must be >= 1");
+  lmc_sampler* s = new (std::nothrow) lmc_sampler();
+  if (!s) return fail(LMC_E_NOMEM, "host allocation failed");
+  lmc_problem pr = cfg->problem;
+  if (pr.prior_kind == LMC_PRIOR_TV_ISO && pr.tv_niter < 1) pr.tv_niter = 1;   // unused by ULPDA; keeps the loader happy
+  int rc = load_problem(&pr, s->prob);
+  if (rc) { delete s; return rc; }
+  s->kind = 1;
+  s->C = cfg->n_chains;
+  s->chain_offset = cfg->chain_offset;
+  s->tau = cfg->tau; s->mu = cfg->mu; s->theta = cfg->theta;
+  s->gfirst = cfg->gfirst != 0; s->cg_niter = cfg->cg_niter; s->warm = cfg->warm != 0;
+  s->z = cfg->z_dev;
+  s->seed = cfg->seed;
+  s->noise_mode = cfg->noise_mode;
+  s->moments = cfg->moments; s->burn_in = cfg->burn_in; s->thin = cfg->thin < 1 ? 1 : cfg->thin;
+  s->base.key0 = (uint32_t)(s->seed & 0xFFFFFFFFu);
+  s->base.key1 = (uint32_t)(s->seed >> 32);
+  s->base.chain_offset = (uint32_t)s->chain_offset;
+  const size_t n = (size_t)s->C * s->prob.H * s->prob.W, img = (size_t)s->prob.H * s->prob.W;
+  hipError_t e = hipSuccess;
+  auto alloc = [&](float** p, size_t count) { if (e == hipSuccess) e = hipMalloc(p, sizeof(float) * count); if (e == hipSuccess) e = hipMemset(*p, 0, sizeof(float) * count); };
+  alloc(&s->x[0], n); alloc(&s->xhat, n); alloc(&s->ydual, 2 * n); alloc(&s->uw, n); alloc(&s->rhs, n);
+  if (s->noise_mode == LMC_NOISE_PHILOX) alloc(&s->xi, n);
+  if (s->prob.data_kind == LMC_DATA_BLUR) {
+    alloc(&s->cr, n); alloc(&s->cp, n); alloc(&s->cq, n); alloc(&s->ctmp, n); alloc(&s->htb, img);
+    if (e == hipSuccess) e = hipMalloc(&s->scal, sizeof(double) * 3 * s->C);
+    if (e == hipSuccess) e = lmc::launch_blur(s->prob.y, s->htb, 1, s->prob.H, s->prob.W, s->prob.taps, 1, nullptr);   // H^T b
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess && s->moments) {
+    const size_t mb = sizeof(double) * img;
+    e = hipMalloc(&s->s1, mb);
+    if (e == hipSuccess) e = hipMalloc(&s->s2, mb);
+    if (e == hipSuccess) e = hipMemset(s->s1, 0, mb);
+    if (e == hipSuccess) e = hipMemset(s->s2, 0, mb);
+  }
+  if (e != hipSuccess) {
+    rc = fail(e == hipErrorOutOfMemory ? LMC_E_NOMEM : LMC_E_HIP, "sampler allocation failed: %s", hipGetErrorString(e));
+    lmc_sampler_destroy(s);
+    return rc;
+  }
+  s->kernel_name = "(no step launched yet)";
+  *out = s;
+  return LMC_OK;
+}
+
+int lmc_sampler_set_dual(lmc_sampler* s, const float* y_dev, void* stream) {
+  if (!s || !y_dev) return fail(LMC_E_INVALID, "NULL argument");
+  if (s->kind != 1) return fail(LMC_E_STATE, "not a ULPDA sampler");
+  HIP_TRY(hipMemcpyAsync(s->ydual, y_dev, sizeof(float) * 2 * (size_t)s->C * s->prob.H * s->prob.W, hipMemcpyDeviceToDevice, S(stream)));
+  return LMC_OK;
+}
+
+int lmc_sampler_get_dual(lmc_sampler* s, float* y_dev, void* stream) {
+  if (!s || !y_dev) return fail(LMC_E_INVALID, "NULL argument");
+  if (s->kind != 1) return fail(LMC_E_STATE, "not a ULPDA sampler");
+  HIP_TRY(hipMemcpyAsync(y_dev, s->ydual, sizeof(float) * 2 * (size_t)s->C * s->prob.H * s->prob.W, hipMemcpyDeviceToDevice, S(stream)));
+  return LMC_OK;
+}
+
+int lmc_sampler_set_steps(lmc_sampler* s, float tau, float mu) {
+  if (!s) return fail(LMC_E_INVALID, "NULL sampler");
+  if (s->kind != 1) return fail(LMC_E_STATE, "not a ULPDA sampler");
+  if (!(tau > 0.f) || !(mu > 0.f)) return fail(LMC_E_INVALID, "tau and mu must be > 0");
+  s->tau = tau; s->mu = mu;
   return LMC_OK;
 }
 

@@ -38,3 +38,16 @@ hipError_t launch_step_stream(StepArgs a, hipStream_t st);
 bool split_supported(const StepArgs& a);
 hipError_t launch_step_split(StepArgs a, hipStream_t st);
 }  // namespace lmc
+
+namespace lmc {
+// ULPDA building blocks (lmc_ulpda.hip)
+hipError_t ulpda_dual_update(const float* xhat, float* y, int64_t C, int H, int W, float mu, float radius, int iso, hipStream_t st);
+hipError_t ulpda_rhs(const float* x, const float* y, const float* z, const float* htb, float* rhs, int64_t C, int H, int W,
+                     float tau, float ts, hipStream_t st);
+hipError_t ulpda_pointwise_prox(const float* v, float* u, const float* b, const float* m, int64_t C, int H, int W, float ts,
+                                int kind, hipStream_t st);
+hipError_t ulpda_finish(float* x, float* xhat, const float* u, const float* xi, int64_t C, int H, int W, float s, float theta,
+                        hipStream_t st);
+hipError_t ulpda_cg_solve(float* u, const float* rhs, float* r, float* p, float* q, float* tmp, double* scal, int64_t C, int H,
+                          int W, const BlurTaps& T, float ts, int niter, hipStream_t st);
+}  // namespace lmc

@@ -232,6 +232,10 @@ __global__ __launch_bounds__(256) void energy_kernel(const float* __restrict__ x
       const float dx = (r + 1 < H) ? xi[p + W] - v : 0.f;
       const float dy = (c + 1 < W) ? xi[p + 1] - v : 0.f;
       ga += (double)sqrtf(fmaf(dx, dx, dy * dy));
+    } else if (E.prior_kind == LMC_PRIOR_TV_ANISO) {
+      const float dx = (r + 1 < H) ? xi[p + W] - v : 0.f;
+      const float dy = (c + 1 < W) ? xi[p + 1] - v : 0.f;
+      ga += (double)fabsf(dx) + (double)fabsf(dy);
     } else if (E.prior_kind == LMC_PRIOR_L1) {
       ga += (double)fabsf(v);
     } else if (E.prior_kind == LMC_PRIOR_L2) {

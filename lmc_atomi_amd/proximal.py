@@ -131,6 +131,7 @@ class L2(ProxOperator):
         self.warm = warm
         self.dims = dims if dims is not None else getattr(Op, "dims", None)
         self._prob = None
+        self._x0 = None          # warm-start vector of the implicit step (stateful, as the reference's L2)
 
     # -- descriptors ---------------------------------------------------------------------
     def descriptor(self):
@@ -172,11 +173,27 @@ class L2(ProxOperator):
         return self._problem().eval(x, 0.0, -1.0, 0.0, 0.0)
 
     def prox(self, x, tau):
-        if self.Op is None:
-            if self.b is None:
-                return x / (1.0 + tau * self.sigma)
-            return (x + tau * self.sigma * self.b) / (1.0 + tau * self.sigma)
-        raise NotImplementedError("implicit L2 step with an operator: handled by UnadjustedLangevinPrimalDual")
+        """``(I + tau*sigma*Op^T Op)^{-1}(x + tau*sigma*Op^T b)`` (pyproximal.L2.prox; in-repo twin algs.py:224-256).
+        With a blur operator: ``niter`` warm-started CG iterations on the GPU (lmc_l2_prox)."""
+        if self.Op is None and self.b is None:
+            return x / (1.0 + tau * self.sigma)
+        prob = self._problem()
+        n = self.dims[0] * self.dims[1]
+        xt = _dev.to_dev(x)
+        n_img = xt.numel() // n
+        lib = _dev.lib()
+        if self.warm and self._x0 is not None and self._x0.numel() == xt.numel():
+            out, warm = self._x0.clone(), 1
+        else:
+            out, warm = torch.empty_like(xt), 0
+        nbytes = lib.lmc_l2_prox_workspace_bytes(n_img, self.dims[0], self.dims[1])
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=xt.device)
+        _capi.check(lib.lmc_l2_prox(C.byref(prob.c), _dev.ptr(xt), _dev.ptr(out), n_img, float(tau), int(self.niter),
+                                    warm, _dev.ptr(ws), _dev.stream_ptr()))
+        torch.cuda.current_stream().synchronize()
+        if self.warm:
+            self._x0 = out.clone()
+        return _dev.like_input(out.reshape(xt.shape), x)
 
 
 class L1(ProxOperator):

@@ -40,14 +40,15 @@ def test_struct_layouts_match_the_header_sizes():
     import subprocess
     import tempfile
     from lmc_atomi_amd import _capi
-    code = '#include <stdio.h>\n#include "lmc_atomi.h"\nint main(){printf("%zu %zu\\n", sizeof(lmc_problem), sizeof(lmc_myula_config));return 0;}\n'
+    code = '#include <stdio.h>\n#include "lmc_atomi.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(lmc_problem), sizeof(lmc_myula_config), sizeof(lmc_ulpda_config));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         src, exe = os.path.join(d, "s.c"), os.path.join(d, "s")
         open(src, "w").write(code)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
-        a, b = map(int, subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split())
+        a, b, c = map(int, subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split())
     assert ctypes.sizeof(_capi.lmc_problem) == a
     assert ctypes.sizeof(_capi.lmc_myula_config) == b
+    assert ctypes.sizeof(_capi.lmc_ulpda_config) == c
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

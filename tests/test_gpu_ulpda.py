@@ -1,0 +1,151 @@
+"""GPU parity of the ULPDA path (algs.py:295-474) and of the implicit L2 data step (row a8), through the C ABI.
+
+The inner solver is `cg_niter` conjugate-gradient iterations in fp32 on the device vs float64 in the oracle; after
+50 iterations both are converged to the same solution, so the tolerance is that of the outer recursion."""
+import numpy as np
+import pytest
+
+from oracle import lmc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+    assert torch.cuda.is_available()
+    import lmc_atomi_amd as la
+    return la
+
+
+@pytest.mark.parametrize("k,shape", [(5, (16, 16)), (7, (24, 18)), (5, (40, 70))])
+def test_l2_implicit_step_matches_oracle(la, k, shape):
+    rng = np.random.default_rng(k)
+    h = np.ones((k, k)) / k ** 2
+    b = rng.normal(100, 20, shape)
+    v = rng.normal(100, 20, (3,) + shape)
+    l2 = la.L2(Op=la.Convolve2D(shape, h), b=b.ravel(), sigma=1 / 0.75 ** 2, niter=50, warm=True)
+    out = l2.prox(v.reshape(3, -1), 0.53)
+    for c in range(3):
+        l2o = O.L2(Op=O.Convolve2D(shape, h), b=b.ravel(), sigma=1 / 0.75 ** 2, niter=200, warm=False)
+        assert rel(out[c], l2o.prox(v[c].ravel(), 0.53)) < 2e-5
+    # a second call is warm-started from the first solution: the residual of the normal equations stays tiny
+    out2 = l2.prox(v.reshape(3, -1), 0.53)
+    assert rel(out2, out) < 1e-5
+    # truncated solve, cold start: same iterate as the oracle's CG after the same number of iterations
+    l2c = la.L2(Op=la.Convolve2D(shape, h), b=b.ravel(), sigma=1 / 0.75 ** 2, niter=3, warm=False)
+    l2oc = O.L2(Op=O.Convolve2D(shape, h), b=b.ravel(), sigma=1 / 0.75 ** 2, niter=3, warm=False)
+    assert rel(l2c.prox(v[0].ravel(), 0.53), l2oc.prox(v[0].ravel(), 0.53)) < 1e-5
+
+
+def test_l2_closed_form_steps(la):
+    shape = (20, 30)
+    rng = np.random.default_rng(0)
+    b = rng.normal(100, 20, shape)
+    v = rng.normal(100, 20, shape)
+    mask = (rng.uniform(size=shape) < 0.5).astype(np.float64)
+    out = la.L2(b=b, sigma=1.7, dims=shape).prox(v.ravel(), 0.4)
+    assert rel(out, ((v + 0.4 * 1.7 * b) / (1 + 0.4 * 1.7)).ravel()) < 1e-6
+    out = la.L2(Op=la.Diagonal(mask, dims=shape), b=b, sigma=1.7, dims=shape).prox(v.ravel(), 0.4)
+    assert rel(out, ((v + 0.4 * 1.7 * mask * b) / (1 + 0.4 * 1.7 * mask ** 2)).ravel()) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_drop_in_ulpda_reproduces_reference_trajectories(la, golden, tag):
+    """la.UnadjustedLangevinPrimalDual(..., rng='pcg64') against trajectories of the reference's own
+    UnadjustedLangevinPrimalDual (tests/golden/algs.npz; inner solver = the oracle's 50-iteration CG)."""
+    g = golden("algs.npz")
+    sigma, tau_reg, tau_myula, gamma_myula, tau0, mu0 = [float(v) for v in g["params"]]
+    ny, nx, k, seed = [int(v) for v in g[f"{tag}_meta"]]
+    h, y = g[f"{tag}_h"], g[f"{tag}_y"]
+    H = la.Convolve2D((ny, nx), h, offset=(k // 2, k // 2))
+    G = la.Gradient((ny, nx))
+    for gfirst in (False, True):
+        gx, gy = g[f"{tag}_ulpda_l21_gfirst{int(gfirst)}_x"], g[f"{tag}_ulpda_l21_gfirst{int(gfirst)}_y"]
+        l2 = la.L2(Op=H, b=y.ravel(), sigma=1 / sigma ** 2, niter=50, warm=True)
+        seen = []
+        xs, ys = la.UnadjustedLangevinPrimalDual(l2, la.L21(ndim=2, sigma=tau_reg), G, tau=tau0, mu=mu0, theta=1.0,
+                                                 x0=np.zeros(ny * nx), gfirst=gfirst, niter=gx.shape[0], seed=seed,
+                                                 returny=True, rng="pcg64", callback=lambda x: seen.append(x[0]))
+        assert xs.shape == gx.shape and ys.shape == gy.shape and len(seen) == gx.shape[0]
+        assert rel(xs, gx) < 1e-4, (tag, gfirst, rel(xs, gx))
+        assert rel(ys, gy) < 1e-3, (tag, gfirst, rel(ys, gy))
+    if f"{tag}_ulpda_l1" in g.files:
+        gx = g[f"{tag}_ulpda_l1"]
+        l2 = la.L2(Op=H, b=y.ravel(), sigma=1 / sigma ** 2, niter=50, warm=True)
+        xs = la.UnadjustedLangevinPrimalDual(l2, la.L1(sigma=tau_reg), G, tau=tau0, mu=mu0, theta=1.0, x0=np.zeros(ny * nx),
+                                             gfirst=False, niter=gx.shape[0], seed=seed, rng="pcg64")
+        assert rel(xs, gx) < 1e-4, rel(xs, gx)
+
+
+def test_ulpda_many_chains_philox_vs_oracle(la):
+    """Batched Philox ULPDA on the GPU == per-chain oracle loops driven by the oracle's Philox field; per-iteration
+    step arrays; energies and moments."""
+    shape = (18, 40)
+    sigma, tau_reg = 0.75, 0.3
+    rng = np.random.default_rng(3)
+    img = np.zeros(shape); img[4:12, 10:30] = 150.0
+    h = np.ones((5, 5)) / 25
+    y = O.blur(img, h, (2, 2)) + rng.normal(0, sigma, shape)
+    C, off, seed, nit = 3, 11, 5, 6
+    taus = np.linspace(0.5, 0.3, nit); mus = np.linspace(1.0, 0.8, nit)
+    l2 = la.L2(Op=la.Convolve2D(shape, h), b=y.ravel(), sigma=1 / sigma ** 2, niter=40, warm=True)
+    smp = la.ULPDASampler(l2, la.L21(sigma=tau_reg), la.Gradient(shape), shape, n_chains=C, tau=taus[0], mu=mus[0], theta=1.0,
+                          gfirst=False, seed=seed, chain_offset=off, moments=True)
+    for it in range(nit):
+        smp.set_steps(taus[it], mus[it])
+        smp.step(1)
+    got = smp.get_state().cpu().numpy()
+    goty = smp.get_dual().cpu().numpy()
+    Gop = O.Gradient(shape)
+    s1 = np.zeros(shape)
+    for c in range(C):
+        l2o = O.L2(Op=O.Convolve2D(shape, h), b=y.ravel(), sigma=1 / sigma ** 2, niter=40, warm=True)
+        noise = np.stack([O.philox_normals(seed, k, [off + c], *shape)[0].ravel().astype(np.float64) for k in range(nit)])
+        xs, ys = O.ulpda(l2o, O.L21(sigma=tau_reg), Gop, np.zeros(shape[0] * shape[1]), taus, mus, theta=1.0, niter=nit,
+                         gfirst=False, returny=True, noise=noise)
+        assert rel(got[c].ravel(), xs[-1]) < 1e-4, (c, rel(got[c].ravel(), xs[-1]))
+        assert rel(goty[c].ravel(), ys[-1]) < 1e-3
+        s1 += xs.sum(axis=0).reshape(shape)
+    m1, m2, cnt = smp.moments()
+    assert cnt == C * nit and rel(m1.cpu().numpy(), s1) < 1e-4
+    f, g = smp.energies()
+    l2o = O.L2(Op=O.Convolve2D(shape, h), b=y.ravel(), sigma=1 / sigma ** 2)
+    assert abs(float(f[0]) - l2o(got[0].ravel())) < 1e-4 * l2o(got[0].ravel())
+    assert abs(float(g[0]) - O.L21(sigma=tau_reg)(Gop.matvec(got[0].ravel()))) < 1e-4 * float(g[0])
+    smp.close()
+
+
+def test_ulpda_identity_data_and_anisotropic_prior(la):
+    shape = (12, 20)
+    rng = np.random.default_rng(4)
+    b = rng.normal(100, 20, shape)
+    nit, seed = 5, 2
+    lf = la.L2(b=b, sigma=1.3, dims=shape)
+    smp = la.ULPDASampler(lf, la.L1(sigma=0.4), la.Gradient(shape), shape, n_chains=1, tau=0.4, mu=0.3, theta=0.5, gfirst=True,
+                          seed=seed, noise="injected")
+    noise = rng.standard_normal((nit, 1) + shape)
+    smp.step(nit, noise=noise)
+    xs = O.ulpda(O.L2(b=b.ravel(), sigma=1.3), O.L1(sigma=0.4), O.Gradient(shape), np.zeros(shape[0] * shape[1]), 0.4, 0.3,
+                 theta=0.5, niter=nit, gfirst=True, noise=noise.reshape(nit, -1))
+    assert rel(smp.get_state().cpu().numpy().ravel(), xs[-1]) < 2e-5
+    smp.close()
+
+
+def test_ulpda_errors(la):
+    shape = (8, 8)
+    lf = la.L2(b=np.zeros(shape), sigma=1.0, dims=shape)
+    with pytest.raises(NotImplementedError):
+        la.ULPDASampler(lf, la.TV(shape, 0.3), la.Gradient(shape), shape, tau=0.1, mu=0.1)
+    with pytest.raises(NotImplementedError):
+        la.ULPDASampler(lf, la.L21(sigma=0.3), la.Identity(64), shape, tau=0.1, mu=0.1)
+    smp = la.MYULASampler(lf, None, shape, tau=0.1, gamma=0.5)
+    from lmc_atomi_amd import _capi, _dev
+    with pytest.raises(la.LMCError):
+        _capi.check(_dev.lib().lmc_sampler_set_steps(smp._h, 0.1, 0.1))   # not a ULPDA handle
