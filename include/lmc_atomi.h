@@ -57,6 +57,11 @@ typedef enum lmc_prior_kind {
   LMC_PRIOR_TV_ANISO = 4 /* ULPDA / energies only: g o A with g = sigma*L1 (prox_lmc_deconv.py:119), dual prox = clip */
 } lmc_prior_kind;
 
+typedef enum lmc_ncvx_kind {
+  LMC_NCVX_NONE = 0,
+  LMC_NCVX_MC_TV = 1    /* minimax-concave TV (Moreau envelope of l1 composed with the gradient), isotropic */
+} lmc_ncvx_kind;
+
 typedef enum lmc_noise_mode {
   LMC_NOISE_PHILOX = 0,   /* counter-based Philox4x32-10 + Box-Muller, keyed by (seed, iteration, global chain, pixel) */
   LMC_NOISE_INJECTED = 1, /* caller supplies xi (parity tests: replaces algs.py:565) */
@@ -83,6 +88,11 @@ typedef struct lmc_problem {
   int32_t tv_niter;         /* LMC_PRIOR_TV_ISO: number of dual iterations (niter_tv = 10) */
   float tv_step;            /* dual step is tv_step / (prox parameter); 0 -> 1/8 */
   const float* tv_betas_host; /* tv_niter momentum coefficients, host; NULL -> UNLocBoX/pyproximal sequence */
+  /* non-log-concave data term of algs.L2_ncvx_tv (algs.py:22-291): f(x) = sigma_f/2||Hx-y||^2 - ncvx_lambda * env_gamma(TV)(x).
+   * LMC_NCVX_MC_TV: Op2 = gradient, isotropic (algs.py:273-277): grad f = sigma_f H^T(Hx-y) - lambda * A^T( A x / max(|A x|, gamma) ) */
+  int32_t ncvx_kind;        /* lmc_ncvx_kind */
+  float ncvx_lambda;        /* lamda (= tau_reg at prox_lmc_deconv.py:106) */
+  float ncvx_gamma;         /* gamma (= gamma_mc = 15 at prox_lmc_deconv.py:40,106) */
 } lmc_problem;
 
 /* ---- library ------------------------------------------------------------------------- */

@@ -17,6 +17,7 @@ ABI_VERSION = 1
 DATA_NONE, DATA_IDENTITY, DATA_BLUR, DATA_MASK = 0, 1, 2, 3
 PRIOR_NONE, PRIOR_L2, PRIOR_L1, PRIOR_TV_ISO, PRIOR_TV_ANISO = 0, 1, 2, 3, 4
 NOISE_PHILOX, NOISE_INJECTED, NOISE_NONE = 0, 1, 2
+NCVX_NONE, NCVX_MC_TV = 0, 1
 MAX_BLUR = 9
 MAX_TV_ITERS = 64
 (EPROX_LAPLACE, EPROX_UNCENTERED_LAPLACE, EPROX_GAUSSIAN, EPROX_GEN_GAUSSIAN_4_3, EPROX_GEN_GAUSSIAN_3_2,
@@ -47,6 +48,9 @@ class lmc_problem(C.Structure):
         ("tv_niter", C.c_int32),
         ("tv_step", C.c_float),
         ("tv_betas_host", C.POINTER(C.c_float)),
+        ("ncvx_kind", C.c_int32),
+        ("ncvx_lambda", C.c_float),
+        ("ncvx_gamma", C.c_float),
     ]
 
 

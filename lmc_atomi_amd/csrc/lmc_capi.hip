@@ -66,6 +66,8 @@ struct Problem {
   int tv_niter = 0;
   float tv_step = 0.125f;
   float betas[lmc::kMaxTvIters] = {};
+  int ncvx_kind = 0;
+  float ncvx_lambda = 0.f, ncvx_gamma = 1.f;
 };
 
 int load_problem(const lmc_problem* p, Problem& q) {
@@ -109,6 +111,11 @@ int load_problem(const lmc_problem* p, Problem& q) {
     default: return fail(LMC_E_INVALID, "unknown prior_kind %d", p->prior_kind);
   }
   if (p->prior_kind != LMC_PRIOR_NONE && !(p->prior_sigma >= 0.f)) return fail(LMC_E_INVALID, "prior_sigma must be >= 0");
+  if (p->ncvx_kind != LMC_NCVX_NONE) {
+    if (p->ncvx_kind != LMC_NCVX_MC_TV) return fail(LMC_E_UNSUPPORTED, "unknown ncvx_kind %d (only LMC_NCVX_MC_TV is built)", p->ncvx_kind);
+    if (!(p->ncvx_gamma > 0.f)) return fail(LMC_E_INVALID, "ncvx_gamma must be > 0");
+    q.ncvx_kind = p->ncvx_kind; q.ncvx_lambda = p->ncvx_lambda; q.ncvx_gamma = p->ncvx_gamma;
+  }
   return LMC_OK;
 }
 
@@ -130,6 +137,9 @@ int make_step_args(const Problem& q, float a, float t, float b, float pt, float 
     A.tv.gamma = gam;
     A.tv.c = q.tv_step / gam;
     std::memcpy(A.tv.betas, q.betas, sizeof(float) * q.tv_niter);
+  }
+  if (t != 0.f && q.ncvx_kind != LMC_NCVX_NONE) {
+    A.ncvx_kind = q.ncvx_kind; A.ncvx_lambda = q.ncvx_lambda; A.ncvx_gamma = q.ncvx_gamma; A.ncvx_inv_gamma = 1.f / q.ncvx_gamma;
   }
   A.a = a; A.t = t; A.b = b; A.s = s;
   A.noise_mode = LMC_NOISE_NONE;
@@ -265,6 +275,7 @@ static lmc::EnergyArgs energy_args(const Problem& q) {
   lmc::EnergyArgs E;
   E.H = q.H; E.W = q.W; E.data_kind = q.data_kind; E.sigma_f = q.sigma_f; E.y = q.y; E.mask = q.mask;
   E.blur = q.taps; E.prior_kind = q.prior_kind; E.prior_sigma = q.prior_sigma;
+  E.ncvx_kind = q.ncvx_kind; E.ncvx_lambda = q.ncvx_lambda; E.ncvx_gamma = q.ncvx_gamma;
   return E;
 }
 

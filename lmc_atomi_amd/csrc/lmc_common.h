@@ -35,6 +35,8 @@ struct StepArgs {
   int prior_kind;
   float prior_p0;     // L2: 1/(1+t*sigma) ; L1: threshold t*sigma
   TvIter tv;
+  int ncvx_kind;             // LMC_NCVX_*: extra term of the data gradient (algs.py:270-291)
+  float ncvx_lambda, ncvx_inv_gamma, ncvx_gamma;
   float a, t, b, s;
   int noise_mode;
   const float* noise;        // [C][H][W] of this iteration (injected)

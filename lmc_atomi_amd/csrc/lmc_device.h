@@ -80,6 +80,24 @@ __device__ __forceinline__ int xcd_logical_block(int b, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
+// ---- MC-TV term of algs.L2_ncvx_tv.grad (algs.py:273-277): A^T( A x / max(|A x|, gamma) ) at pixel (i,j) ----------
+// x_rc: x at row offset r (m = -1, 0 = same, p = +1) and column offset c.  has_*: the neighbour exists inside the image.
+// |A x| = 0 is mapped to 1e-9 by the reference before min(1/gamma, 1/|A x|): identical to 1/max(|A x|, gamma).
+__device__ __forceinline__ float mc_tv_grad(float xm0, float xmp, float x0m, float x00, float x0p, float xpm, float xp0,
+                                            bool has_up, bool has_down, bool has_left, bool has_right, float gamma) {
+  // weights and differences at (i,j), (i-1,j), (i,j-1)
+  const float dx00 = has_down ? xp0 - x00 : 0.f, dy00 = has_right ? x0p - x00 : 0.f;
+  const float w00 = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(fmaf(dx00, dx00, dy00 * dy00)), gamma));
+  const float dxm0 = has_up ? x00 - xm0 : 0.f;                       // (i-1,j) always has a row below it
+  const float dym0 = (has_up && has_right) ? xmp - xm0 : 0.f;
+  const float wm0 = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(fmaf(dxm0, dxm0, dym0 * dym0)), gamma));
+  const float dy0m = has_left ? x00 - x0m : 0.f;                     // (i,j-1) always has a column to its right
+  const float dx0m = (has_left && has_down) ? xpm - x0m : 0.f;
+  const float w0m = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(fmaf(dx0m, dx0m, dy0m * dy0m)), gamma));
+  // A^T v = -div v
+  return -((w00 * dx00 - wm0 * dxm0) + (w00 * dy00 - w0m * dy0m));
+}
+
 // ---- shared by the streaming step kernels ---------------------------------------------------------
 constexpr int kPad = 8;  // zero columns on both sides of LDS rows (>= kMaxBlur - 1)
 #ifdef LMC_BOUNDS_CHECK   // debug build: out-of-range global accesses are recorded and skipped, never issued

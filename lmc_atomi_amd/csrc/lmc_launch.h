@@ -13,6 +13,8 @@ struct EnergyArgs {
   BlurTaps blur;
   int prior_kind;
   float prior_sigma;
+  int ncvx_kind;          // f -= ncvx_lambda * sum huber_gamma(|grad x|)  (algs.py:173-190, MC-TV isotropic)
+  float ncvx_lambda, ncvx_gamma;
 };
 
 hipError_t launch_step_tile(StepArgs a, hipStream_t st);

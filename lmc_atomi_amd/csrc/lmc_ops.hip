@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void energy_kernel(const float* __restrict__ x
   const int H = E.H, W = E.W;
   const size_t img = (size_t)H * W;
   const float* xi = x + (size_t)blockIdx.y * img;
-  double fa = 0.0, ga = 0.0;
+  double fa = 0.0, ga = 0.0, na = 0.0;
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < img; p += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(p / W), c = (int)(p - (size_t)r * W);
     const float v = xi[p];
@@ -228,6 +228,13 @@ __global__ __launch_bounds__(256) void energy_kernel(const float* __restrict__ x
       res = E.mask[p] * v - E.y[p];
     }
     fa += (double)res * (double)res;
+    if (E.ncvx_kind == LMC_NCVX_MC_TV) {   // Moreau envelope of |.| at |grad x|: Huber, subtracted with weight lambda
+      const float dx = (r + 1 < H) ? xi[p + W] - v : 0.f;
+      const float dy = (c + 1 < W) ? xi[p + 1] - v : 0.f;
+      const float e = sqrtf(fmaf(dx, dx, dy * dy));
+      const double hub = e <= E.ncvx_gamma ? 0.5 * (double)e * e / E.ncvx_gamma : (double)e - 0.5 * E.ncvx_gamma;
+      na += hub;
+    }
     if (E.prior_kind == LMC_PRIOR_TV_ISO) {
       const float dx = (r + 1 < H) ? xi[p + W] - v : 0.f;
       const float dy = (c + 1 < W) ? xi[p + 1] - v : 0.f;
@@ -244,8 +251,9 @@ __global__ __launch_bounds__(256) void energy_kernel(const float* __restrict__ x
   }
   const double ft = block_sum(fa, scratch);
   const double gt = block_sum(ga, scratch);
+  const double nt = E.ncvx_kind != LMC_NCVX_NONE ? block_sum(na, scratch) : 0.0;
   if (threadIdx.x == 0) {
-    if (f_out) unsafeAtomicAdd(&f_out[blockIdx.y], 0.5 * (double)E.sigma_f * ft);
+    if (f_out) unsafeAtomicAdd(&f_out[blockIdx.y], 0.5 * (double)E.sigma_f * ft - (double)E.ncvx_lambda * nt);
     if (g_out) unsafeAtomicAdd(&g_out[blockIdx.y], (double)E.prior_sigma * gt);
   }
 }

@@ -332,6 +332,13 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
       const float mk = S.mpre[U];
       g = A.sigma_f * mk * fmaf(mk, x, -S.ypre[U]);
     }
+    if (A.ncvx_kind == LMC_NCVX_MC_TV) {   // - lambda * A^T(A x / max(|A x|, gamma))  (algs.py:273-277, 291)
+      const float* xm = xb + (G::RB - G::D - 1) * BWP;   // row o-1
+      const float* xp = xb + (G::RB - G::D + 1) * BWP;   // row o+1
+      const float* x0 = xb + (G::RB - G::D) * BWP;
+      g -= A.ncvx_lambda * mc_tv_grad(xm[0], xm[1], x0[-1], x, x0[1], xp[-1], xp[0], o > 0, o + 1 < H, c.col > 0,
+                                      c.col + 1 < W, A.ncvx_gamma);
+    }
     float px;
     if (K > 0) {
       px = prox_o;

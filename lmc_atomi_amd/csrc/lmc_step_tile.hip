@@ -175,6 +175,10 @@ __global__ __launch_bounds__(kStepThreads) void myula_step_tile_kernel(const Ste
       const float mk = P.mask[gi];
       g = P.sigma_f * mk * fmaf(mk, x, -P.y[gi]);
     }
+    if (P.ncvx_kind == LMC_NCVX_MC_TV) {   // - lambda * A^T(A x / max(|A x|, gamma))  (algs.py:273-277, 291)
+      g -= P.ncvx_lambda * mc_tv_grad(xs[p - PW], xs[p - PW + 1], xs[p - 1], x, xs[p + 1], xs[p + PW - 1], xs[p + PW],
+                                      gr > 0, gr + 1 < H, gc > 0, gc + 1 < W, P.ncvx_gamma);
+    }
     float px;
     if (TV) {
       px = S[p];
@@ -252,6 +256,7 @@ hipError_t launch_step_tile(StepArgs a, hipStream_t st) {
   int halo = 0;
   if (a.data_kind == LMC_DATA_BLUR) halo = max(a.blur.kh, a.blur.kw) - 1;
   if (tv) halo = max(halo, a.tv.niter);
+  if (a.ncvx_kind != LMC_NCVX_NONE) halo = max(halo, 1);
   TilePlan tp;
   if (!plan_tiles(a.H, a.W, halo, tv, 160 * 1024, tp)) return hipErrorInvalidConfiguration;
   a.TH = tp.TH; a.TW = tp.TW; a.HL = tp.HL; a.PH = tp.PH; a.PW = tp.PW;

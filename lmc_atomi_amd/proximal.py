@@ -89,6 +89,9 @@ class _Problem:
                 raise ValueError("tv_betas must have tv_niter entries")
             self._keep.append(b)
             p.tv_betas_host = _dev.fptr(b)
+        p.ncvx_kind = int(data.get("ncvx_kind", _capi.NCVX_NONE))
+        p.ncvx_lambda = float(data.get("ncvx_lambda", 0.0))
+        p.ncvx_gamma = float(data.get("ncvx_gamma", 1.0))
         self.c = p
 
     def eval(self, x, a, t, b, pt):
@@ -296,3 +299,55 @@ class TV(ProxOperator):
 
     def prox(self, x, tau):
         return self._problem().eval(x, 0.0, 0.0, 1.0, float(tau))
+
+
+class L2_ncvx_tv(ProxOperator):
+    r"""Non-log-concave data term -- drop-in for the reference's own class ``algs.L2_ncvx_tv`` (algs.py:22-291):
+    ``f(x) = sigma/2 ||Op x - b||^2 - lamda * env_gamma(g)(Op2 x)``, same constructor arguments.
+
+    Built on the GPU: the MC-TV isotropic branch used by prox_lmc_deconv.py:106-108 (``Op2 = Gradient``,
+    ``isotropic=True``): value (algs.py:173-190) and gradient (algs.py:270-291,
+    ``grad = sigma Op^T(Op x - b) - lamda * Op2^T( Op2 x / max(|Op2 x|, gamma) )``), fused into the sampler step.
+    Not built: ME-TV (``Op2=None``, TV prox with niter_l2 = 50 inside the gradient, algs.py:282), anisotropic MC-TV
+    and the implicit ``prox`` (algs.py:201-267) -- they raise.
+    """
+
+    def __init__(self, dims, Op=None, Op2=None, b=None, q=None, sigma=1., alpha=1., lamda=1., gamma=.5, qgrad=True,
+                 isotropic=False, niter=10, rtol=1e-4, x0=None, warm=True, densesolver=None, kwargs_solver=None):
+        super().__init__(Op, True)
+        from .operators import Gradient
+        if q is not None:
+            raise NotImplementedError("q (linear term) has no device functor")
+        if Op2 is None:
+            raise NotImplementedError("ME-TV (Op2=None): TV prox inside the gradient is not built on the GPU yet")
+        if not isinstance(Op2, Gradient) or not isotropic:
+            raise NotImplementedError("only the isotropic MC-TV branch (Op2=Gradient, isotropic=True) is built")
+        if not isinstance(Op, Convolve2D) or b is None:
+            raise NotImplementedError("Op must be a Convolve2D and b given (prox_lmc_deconv.py:106)")
+        self.dims = (int(dims[0]), int(dims[1]))
+        self.Op2 = Op2
+        self.b = b
+        self.sigma, self.lamda, self.gamma = float(sigma), float(lamda), float(gamma)
+        self.isotropic = isotropic
+        self.niter = niter
+        self.warm = warm
+        self._prob = None
+
+    def descriptor(self):
+        return {"data_kind": _capi.DATA_BLUR, "sigma_f": self.sigma, "y": self.b, "h": self.Op.h, "offset": self.Op.offset,
+                "ncvx_kind": _capi.NCVX_MC_TV, "ncvx_lambda": self.lamda, "ncvx_gamma": self.gamma}
+
+    def _problem(self):
+        if self._prob is None:
+            self._prob = _Problem(self.dims, data=self.descriptor())
+        return self._prob
+
+    def __call__(self, x):
+        f, _ = self._problem().energies(x)
+        return float(f[0]) if f.numel() == 1 else (f if isinstance(x, torch.Tensor) else f.cpu().numpy())
+
+    def grad(self, x):
+        return self._problem().eval(x, 0.0, -1.0, 0.0, 0.0)
+
+    def prox(self, x, tau):
+        raise NotImplementedError("L2_ncvx_tv.prox (algs.py:201-267, used by ULPDA with the non-convex term) is not built")

@@ -1,0 +1,88 @@
+"""GPU parity of the non-log-concave data term algs.L2_ncvx_tv (MC-TV branch), against values produced by the
+reference's own class (tests/golden/algs.npz) and against the oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import lmc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+    assert torch.cuda.is_available()
+    import lmc_atomi_amd as la
+    return la
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_mc_tv_value_grad_and_myula_match_reference_class(la, golden, tag):
+    g = golden("algs.npz")
+    sigma, tau_reg, tau_myula, gamma_myula, tau0, mu0 = [float(v) for v in g["params"]]
+    ny, nx, k, seed = [int(v) for v in g[f"{tag}_meta"]]
+    h, y = g[f"{tag}_h"], g[f"{tag}_y"]
+    H = la.Convolve2D((ny, nx), h, offset=(k // 2, k // 2))
+    G = la.Gradient((ny, nx))
+    xt = g[f"{tag}_ncvx_x"]
+    for variant in ("tile", "auto"):
+        la.set_step_variant(variant)
+        mc = la.L2_ncvx_tv(dims=(ny, nx), Op=H, Op2=G, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=15.0,
+                           isotropic=True, niter=50, warm=True)
+        got = mc.grad(xt.copy())
+        ref = g[f"{tag}_ncvx_mc_grad"]
+        # the data part cancels Hx ~ 200 against y ~ 200 (see test_l2_grad_and_value): scale-aware bound + loose rel
+        l2o = O.L2(Op=O.Convolve2D((ny, nx), h, offset=(k // 2, k // 2)), b=y.ravel(), sigma=1 / sigma ** 2)
+        scale = (1 / sigma ** 2) * (np.linalg.norm(l2o.Op.rmatvec(l2o.Op.matvec(xt))) + np.linalg.norm(l2o.Op.rmatvec(y.ravel())))
+        assert np.linalg.norm(got - ref) < 2e-7 * scale and rel(got, ref) < 1e-4, (variant, rel(got, ref))
+        val = float(g[f"{tag}_ncvx_mc_val"])
+        assert abs(mc(xt.copy()) - val) < 1e-5 * abs(val)
+        gx = g[f"{tag}_myula_mc_tv"]
+        out = la.MoreauYosidaUnadjustedLangevin(mc, la.TV((ny, nx), sigma=tau_reg, niter=10), np.zeros(ny * nx),
+                                                tau=tau_myula, gamma=gamma_myula, niter=gx.shape[0], seed=seed, rng="pcg64")
+        assert rel(out, gx) < 5e-5, (variant, rel(out, gx))
+    la.set_step_variant("auto")
+
+
+def test_mc_tv_large_image_all_kernels_agree(la):
+    """The MC-TV term through the tile and the split kernels on a 512-wide image (row / column boundaries, both
+    |grad x| regimes: below and above gamma)."""
+    rng = np.random.default_rng(0)
+    shape = (96, 512)
+    img = np.zeros(shape); img[20:60, 100:400] = 200.0
+    h = np.ones((5, 5)) / 25
+    y = O.blur(img, h, (2, 2)) + rng.normal(0, 0.75, shape)
+    x0 = img[None] + rng.normal(0, 20.0, (2,) + shape)      # differences well above and below gamma = 15
+    outs = {}
+    for v in ("tile", "split"):
+        la.set_step_variant(v)
+        mc = la.L2_ncvx_tv(dims=shape, Op=la.Convolve2D(shape, h), Op2=la.Gradient(shape), b=y.ravel(), sigma=1 / 0.5625,
+                           lamda=0.3, gamma=15.0, isotropic=True)
+        smp = la.MYULASampler(mc, la.TV(shape, sigma=0.3, niter=10), shape, n_chains=2, tau=0.1125, gamma=0.5625, seed=4)
+        smp.set_state(x0)
+        smp.step(3)
+        outs[v] = smp.get_state().cpu().numpy()
+        assert v in smp.kernel_name
+        smp.close()
+    la.set_step_variant("auto")
+    assert rel(outs["split"], outs["tile"]) < 2e-6
+    mco = O.L2NcvxTV(shape, Op=O.Convolve2D(shape, h), Op2=O.Gradient(shape), b=y.ravel(), sigma=1 / 0.5625, lamda=0.3, gamma=15.0)
+    mc = la.L2_ncvx_tv(dims=shape, Op=la.Convolve2D(shape, h), Op2=la.Gradient(shape), b=y.ravel(), sigma=1 / 0.5625,
+                       lamda=0.3, gamma=15.0, isotropic=True)
+    gm = mc.grad(x0[0].ravel()) - la.L2(Op=la.Convolve2D(shape, h), b=y.ravel(), sigma=1 / 0.5625).grad(x0[0].ravel())
+    assert rel(gm, -0.3 * mco.grad_moreau(x0[0].ravel())) < 1e-4
+
+
+def test_unbuilt_branches_raise(la):
+    shape = (8, 8)
+    H = la.Convolve2D(shape, np.ones((5, 5)) / 25)
+    with pytest.raises(NotImplementedError):
+        la.L2_ncvx_tv(dims=shape, Op=H, b=np.zeros(64), isotropic=True)                       # ME-TV
+    with pytest.raises(NotImplementedError):
+        la.L2_ncvx_tv(dims=shape, Op=H, Op2=la.Gradient(shape), b=np.zeros(64), isotropic=False)
