@@ -10,9 +10,12 @@ from .algs import (MYULAResult, MYULASampler, MoreauYosidaUnadjustedLangevin, UL
                    UnadjustedLangevinPrimalDual, mean_var_from_moments,
                    set_step_variant)
 
+from . import metrics
+from .metrics import MetricsCallback, mean_squared_error, peak_signal_noise_ratio, signal_noise_ratio
 from .sharding import allreduce_moments, chain_shard, posterior_mean_var, sharded_myula
 
 __all__ = [
+    "metrics", "MetricsCallback", "mean_squared_error", "peak_signal_noise_ratio", "signal_noise_ratio",
     "allreduce_moments", "chain_shard", "posterior_mean_var", "sharded_myula",
     "LMCError", "Convolve2D", "Diagonal", "Gradient", "Identity", "LinearOperator",
     "L1", "L2", "L21", "TV", "L2_ncvx_tv", "ProxOperator", "fgp_betas",
