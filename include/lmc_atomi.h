@@ -239,7 +239,8 @@ int lmc_sampler_get_dual(lmc_sampler* s, float* y_dev, void* stream);
 int lmc_sampler_set_steps(lmc_sampler* s, float tau, float mu);
 
 /* Step-kernel variant used by lmc_sampler_step / lmc_fused_eval: 0 = auto (default), 1 = LDS-tiled,
- * 2 = streaming register pipeline (one wave group), 3 = the same pipeline split over two wave groups.  Returns the previous setting (>= 0) or a negative lmc_status.
+ * 2 = streaming register pipeline (one wave group), 3 = the same pipeline split over two wave groups,
+ * 4 = HBM-bound tiled kernel for closed-form priors.  Returns the previous setting (>= 0) or a negative lmc_status.
  * Both variants compute the same update; the switch exists for A/B tests and profiles. */
 int lmc_set_step_variant(int32_t variant);
 

@@ -154,13 +154,20 @@ void sanitize_pointers(lmc::StepArgs& A) {
   if (!A.noise) A.noise = A.x_in;
 }
 
-int g_variant = 0;  // 0 auto, 1 tile, 2 stream, 3 split
+int g_variant = 0;  // 0 auto, 1 tile, 2 stream, 3 split, 4 point
 
 // Picks the step-kernel variant.  auto: the split streaming pipeline (two wave groups, 4 waves/SIMD) when
 // it covers the configuration (W <= 512, separable blur <= 7x7, supported K), else the LDS-tiled kernel.
 hipError_t launch_step(const lmc::StepArgs& A, hipStream_t st, const char** name) {
   int v = g_variant;
-  if (v == 0) v = lmc::split_supported(A) ? 3 : (lmc::stream_supported(A) ? 2 : 1);
+  // auto: split pipeline when it covers the configuration (W <= 512); for wider images the tiled kernels:
+  // "point" for closed-form priors with a separable blur, else the general LDS-tiled kernel
+  if (v == 0) v = lmc::split_supported(A) ? 3 : (lmc::point_supported(A) ? 4 : (lmc::stream_supported(A) ? 2 : 1));
+  if (v == 4) {
+    if (!lmc::point_supported(A)) return hipErrorInvalidConfiguration;
+    if (name) *name = "myula_step_point_kernel";
+    return lmc::launch_step_point(A, st);
+  }
   if (v == 3) {
     if (!lmc::split_supported(A)) return hipErrorInvalidConfiguration;
     if (name) *name = "myula_step_split_kernel";
@@ -678,7 +685,7 @@ int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_lau
 const char* lmc_sampler_kernel_name(const lmc_sampler* s) { return s ? s->kernel_name.c_str() : ""; }
 
 int lmc_set_step_variant(int32_t variant) {
-  if (variant < 0 || variant > 3) return fail(LMC_E_INVALID, "variant must be 0 (auto), 1 (tile), 2 (stream) or 3 (split)");
+  if (variant < 0 || variant > 4) return fail(LMC_E_INVALID, "variant must be 0 (auto), 1 (tile), 2 (stream), 3 (split) or 4 (point)");
   const int prev = g_variant;
   g_variant = variant;
   return prev;

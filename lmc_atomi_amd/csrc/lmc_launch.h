@@ -36,6 +36,9 @@ namespace lmc {
 // streaming register-pipeline variant (lmc_step_stream.hip)
 bool stream_supported(const StepArgs& a);
 hipError_t launch_step_stream(StepArgs a, hipStream_t st);
+// HBM-bound tiled kernel for closed-form priors (lmc_step_point.hip)
+bool point_supported(const StepArgs& a);
+hipError_t launch_step_point(StepArgs a, hipStream_t st);
 // split streaming variant: the same pipeline over two wave groups (lmc_step_split.hip)
 bool split_supported(const StepArgs& a);
 hipError_t launch_step_split(StepArgs a, hipStream_t st);

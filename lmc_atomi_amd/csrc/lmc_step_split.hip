@@ -390,6 +390,11 @@ __global__ __launch_bounds__(128 * NW) void myula_step_split_kernel(const StepAr
 
   const int T = H + G::D;
   constexpr int t_lo = (G::D + 3) & ~3;
+#ifdef LMC_NO_STEADY
+  constexpr bool kSteady = false;
+#else
+  constexpr bool kSteady = true;
+#endif
 #ifdef LMC_SPLIT_ONLY_B
   if (false) {
 #else
@@ -420,24 +425,18 @@ __global__ __launch_bounds__(128 * NW) void myula_step_split_kernel(const StepAr
     }
     __syncthreads();
     int tm = 0;
-    for (int t0 = 0; t0 < T; t0 += 4) {
-#ifdef LMC_NO_STEADY
-      const bool steady = false;
-#else
-      const bool steady = (t0 >= t_lo) && (t0 + 3 + 2 < H);
-#endif
-      if (steady) {
-        split_tick_a<K, NW, KT, 0, false>(A, t0 + 0, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_a<K, NW, KT, 1, false>(A, t0 + 1, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_a<K, NW, KT, 2, false>(A, t0 + 2, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_a<K, NW, KT, 3, false>(A, t0 + 3, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-      } else {
-        split_tick_a<K, NW, KT, 0, true>(A, t0 + 0, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_a<K, NW, KT, 1, true>(A, t0 + 1, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_a<K, NW, KT, 2, true>(A, t0 + 2, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_a<K, NW, KT, 3, true>(A, t0 + 3, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-      }
-    }
+#define LMC_A_GROUP(EDGE_)                                                                                   \
+    split_tick_a<K, NW, KT, 0, EDGE_>(A, t0 + 0, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;               \
+    split_tick_a<K, NW, KT, 1, EDGE_>(A, t0 + 1, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;               \
+    split_tick_a<K, NW, KT, 2, EDGE_>(A, t0 + 2, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;               \
+    split_tick_a<K, NW, KT, 3, EDGE_>(A, t0 + 3, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
+    // three loops in sequence: fill (general ticks), steady (predicate-free ticks), drain (general ticks)
+    int t0 = 0;
+    const int t_hi = kSteady ? ((H - 5 - 3) & ~3) : 0;   // last group start with t0 + 3 + 4 < H (prefetch distance 4)
+    for (; t0 < T && (t0 < t_lo || !kSteady || t0 > t_hi); t0 += 4) { LMC_A_GROUP(true) }
+    if (kSteady) for (; t0 <= t_hi; t0 += 4) { LMC_A_GROUP(false) }
+    for (; t0 < T; t0 += 4) { LMC_A_GROUP(true) }
+#undef LMC_A_GROUP
 #ifdef LMC_SPLIT_ONLY_A
   } else if (false) {
 #else
@@ -468,24 +467,17 @@ __global__ __launch_bounds__(128 * NW) void myula_step_split_kernel(const StepAr
     }
     __syncthreads();
     int tm = 0;
-    for (int t0 = 0; t0 < T; t0 += 4) {
-#ifdef LMC_NO_STEADY
-      const bool steady = false;
-#else
-      const bool steady = (t0 >= t_lo) && (t0 + 3 + 2 < H);
-#endif
-      if (steady) {
-        split_tick_b<K, NW, KT, 0, false>(A, t0 + 0, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_b<K, NW, KT, 1, false>(A, t0 + 1, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_b<K, NW, KT, 2, false>(A, t0 + 2, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_b<K, NW, KT, 3, false>(A, t0 + 3, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-      } else {
-        split_tick_b<K, NW, KT, 0, true>(A, t0 + 0, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_b<K, NW, KT, 1, true>(A, t0 + 1, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_b<K, NW, KT, 2, true>(A, t0 + 2, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-        split_tick_b<K, NW, KT, 3, true>(A, t0 + 3, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
-      }
-    }
+#define LMC_B_GROUP(EDGE_)                                                                                   \
+    split_tick_b<K, NW, KT, 0, EDGE_>(A, t0 + 0, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;               \
+    split_tick_b<K, NW, KT, 1, EDGE_>(A, t0 + 1, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;               \
+    split_tick_b<K, NW, KT, 2, EDGE_>(A, t0 + 2, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;               \
+    split_tick_b<K, NW, KT, 3, EDGE_>(A, t0 + 3, tm, c, S); tm = (tm + 1 == RB) ? 0 : tm + 1;
+    int t0 = 0;
+    const int t_hi = kSteady ? ((H - 5 - 3) & ~3) : 0;
+    for (; t0 < T && (t0 < t_lo || !kSteady || t0 > t_hi); t0 += 4) { LMC_B_GROUP(true) }
+    if (kSteady) for (; t0 <= t_hi; t0 += 4) { LMC_B_GROUP(false) }
+    for (; t0 < T; t0 += 4) { LMC_B_GROUP(true) }
+#undef LMC_B_GROUP
   }
 }
 

@@ -232,7 +232,8 @@ def test_stream_and_tile_variants_agree(la):
              (la.L2(Op=la.Convolve2D(shape, h), b=y, sigma=1.7), None)]
     for pf, pg in cases:
         outs = {}
-        for v in ("tile", "stream", "split"):
+        variants = ("tile", "stream", "split") if isinstance(pg, la.TV) else ("tile", "stream", "split", "point")
+        for v in variants:
             la.set_step_variant(v)
             smp = la.MYULASampler(pf, pg, shape, n_chains=3, tau=0.1125, gamma=0.5625, seed=8, chain_offset=5)
             smp.set_state(img)
@@ -240,6 +241,8 @@ def test_stream_and_tile_variants_agree(la):
             outs[v] = smp.get_state().cpu().numpy()
             smp.close()
         assert rel(outs["stream"], outs["tile"]) < 2e-6 and rel(outs["split"], outs["tile"]) < 2e-6
+        if "point" in outs:
+            assert rel(outs["point"], outs["tile"]) < 2e-6
     # a configuration the streaming kernel does not cover (K = 16): forcing it is an error, the default falls back
     shape = (40, 96)
     img, h, y = synth(*shape, seed=1)
@@ -252,6 +255,30 @@ def test_stream_and_tile_variants_agree(la):
     la.set_step_variant("auto")
     smp.step(1)
     assert "tile" in smp.kernel_name
+
+
+def test_wide_images_use_tiled_kernels(la, variant):
+    """W > 512 (e.g. the reference's 667 x 877 einstein image, prox_lmc_deconv.py:46): closed-form priors run on the
+    'point' kernel, TV on the LDS-tiled kernel; both against the oracle with injected noise."""
+    if variant != "auto":
+        pytest.skip("dispatch test")
+    rng = np.random.default_rng(9)
+    shape = (40, 877)
+    img, h, y = synth(*shape, seed=5)
+    noise = rng.standard_normal((2, 2) + shape)
+    x0 = img[None] + rng.normal(0, 10, (2,) + shape)
+    for pg, kern, prior in [(la.L1(sigma=0.3), "point", {"kind": "l1", "sigma": 0.3, "t": 0.5625}),
+                            (la.TV(shape, sigma=0.3, niter=4), "tile", {"kind": "tv", "sigma": 0.3, "niter": 4, "t": 0.5625})]:
+        pf = la.L2(Op=la.Convolve2D(shape, h), b=y, sigma=1 / 0.5625)
+        smp = la.MYULASampler(pf, pg, shape, n_chains=2, tau=0.1125, gamma=0.5625, noise="injected")
+        smp.set_state(x0)
+        smp.step(2, noise=noise)
+        assert kern in smp.kernel_name, smp.kernel_name
+        x = x0.copy()
+        for it in range(2):
+            x = O.myula_step(x, y, h, (2, 2), 1 / 0.5625, 0.1125, 0.5625, prior, noise[it])
+        assert rel(smp.get_state().cpu().numpy(), x) < 2e-5
+        smp.close()
 
 
 # ------------------------------------------------------------------ RNG rung (R3)
