@@ -324,8 +324,12 @@ int lmc_l2_prox(const lmc_problem* prob, const float* x_dev, float* out_dev, int
   HIP_TRY(lmc::launch_blur(q.y, tmp, 1, q.H, q.W, q.taps, 1, st));
   // ulpda_rhs computes x - tau*(A^T ydual) + ts*htb; with a zero dual field it is x + ts*htb.  The dual field needs 2n
   // floats: use r and p (both overwritten later by the solver) as a zeroed [n_img][2][H][W] field.
-  HIP_TRY(hipMemsetAsync(r, 0, sizeof(float) * 2 * n, st));
-  HIP_TRY(lmc::ulpda_rhs(x_dev, r, nullptr, tmp, rhs, n_img, q.H, q.W, 0.f, ts, st));
+  if (q.ncvx_kind == LMC_NCVX_MC_TV) {
+    HIP_TRY(lmc::ulpda_ncvx_rhs(x_dev, tmp, rhs, n_img, q.H, q.W, tau * q.ncvx_lambda, q.ncvx_gamma, ts, st));
+  } else {
+    HIP_TRY(hipMemsetAsync(r, 0, sizeof(float) * 2 * n, st));
+    HIP_TRY(lmc::ulpda_rhs(x_dev, r, nullptr, tmp, rhs, n_img, q.H, q.W, 0.f, ts, st));
+  }
   if (!warm) HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(float) * n, st));
   HIP_TRY(lmc::ulpda_cg_solve(out_dev, rhs, r, p, qq, tmp, scal, n_img, q.H, q.W, q.taps, ts, niter, st));
   return LMC_OK;
@@ -511,6 +515,10 @@ static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, h
     if (s->gfirst)   // y <- proxdual(y + mu A xhat)   (algs.py:436)
       HIP_TRY(lmc::ulpda_dual_update(s->xhat, s->ydual, C, H, W, s->mu, s->prob.prior_sigma, iso, st));
     // v = x - tau (A^T y + z) [+ tau sigma H^T b]      (algs.py:437-440 / 443-446)
+    if (s->prob.ncvx_kind == LMC_NCVX_MC_TV) {   // L2_ncvx_tv.prox pre-step (algs.py:213-217), then + tau sigma H^T b (:225)
+      HIP_TRY(lmc::ulpda_rhs(x, s->ydual, s->z, nullptr, s->ctmp, C, H, W, s->tau, ts, st));
+      HIP_TRY(lmc::ulpda_ncvx_rhs(s->ctmp, s->htb, s->rhs, C, H, W, s->tau * s->prob.ncvx_lambda, s->prob.ncvx_gamma, ts, st));
+    } else
     HIP_TRY(lmc::ulpda_rhs(x, s->ydual, s->z, s->prob.data_kind == LMC_DATA_BLUR ? s->htb : nullptr, s->rhs, C, H, W, s->tau, ts, st));
     const float* u = s->rhs;
     if (s->prob.data_kind == LMC_DATA_BLUR) {
@@ -555,6 +563,8 @@ int lmc_ulpda_create(const lmc_ulpda_config* cfg, lmc_sampler** out) {
     return fail(LMC_E_UNSUPPORTED, "ULPDA needs g o A with g = L21 (LMC_PRIOR_TV_ISO) or L1 (LMC_PRIOR_TV_ANISO)");
   if (!(cfg->problem.prior_sigma > 0.f)) return fail(LMC_E_INVALID, "prior_sigma (dual ball radius) must be > 0");
   if (cfg->problem.data_kind == LMC_DATA_BLUR && cfg->cg_niter < 1) return fail(LMC_E_INVALID, "cg_niter must be >= 1");
+  if (cfg->problem.ncvx_kind != LMC_NCVX_NONE && cfg->problem.data_kind != LMC_DATA_BLUR)
+    return fail(LMC_E_UNSUPPORTED, "the non-convex term is built for the blur data term only (prox_lmc_deconv.py:106)");
   lmc_sampler* s = new (std::nothrow) lmc_sampler();
   if (!s) return fail(LMC_E_NOMEM, "host allocation failed");
   lmc_problem pr = cfg->problem;

@@ -65,6 +65,33 @@ __global__ __launch_bounds__(256) void ulpda_rhs_kernel(const float* __restrict_
   }
 }
 
+// rhs = v + coef * A^T( A v / max(|A v|, gamma) ) + ts * Htb : the in-place pre-step of L2_ncvx_tv.prox (algs.py:213-217)
+// followed by the right-hand side of its linear solve (:225).  v and rhs must be different buffers.
+__global__ __launch_bounds__(256) void ulpda_ncvx_rhs_kernel(const float* __restrict__ v, const float* __restrict__ htb,
+                                                             float* __restrict__ rhs, int H, int W, int64_t C, float coef,
+                                                             float gamma, float ts) {
+  const size_t img = (size_t)H * W, total = img * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i % img;
+    const int r = (int)(p / W), c = (int)(p - (size_t)r * W);
+    const bool up = r > 0, down = r + 1 < H, left = c > 0, right = c + 1 < W;
+    const float x00 = v[i];
+    const float xm0 = up ? v[i - W] : 0.f, xmp = (up && right) ? v[i - W + 1] : 0.f;
+    const float x0m = left ? v[i - 1] : 0.f, x0p = right ? v[i + 1] : 0.f;
+    const float xpm = (down && left) ? v[i + W - 1] : 0.f, xp0 = down ? v[i + W] : 0.f;
+    float out = fmaf(coef, mc_tv_grad(xm0, xmp, x0m, x00, x0p, xpm, xp0, up, down, left, right, gamma), x00);
+    if (htb) out = fmaf(ts, htb[p], out);
+    rhs[i] = out;
+  }
+}
+
+hipError_t ulpda_ncvx_rhs(const float* v, const float* htb, float* rhs, int64_t C, int H, int W, float coef, float gamma, float ts,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(ulpda_ncvx_rhs_kernel, dim3(grid1d((size_t)H * W * C, 256)), dim3(256), 0, st, v, htb, rhs, H, W, C, coef,
+                     gamma, ts);
+  return hipGetLastError();
+}
+
 // q = p + ts * (second operand already holds H^T H p): q = p + ts*hthp ; accumulate dot(p, q) per chain
 __global__ __launch_bounds__(256) void cg_q_kernel(const float* __restrict__ p, float* __restrict__ q /* in: HtHp, out: q */,
                                                    size_t img, float ts, double* __restrict__ pq) {

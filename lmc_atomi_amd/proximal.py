@@ -307,9 +307,10 @@ class L2_ncvx_tv(ProxOperator):
 
     Built on the GPU: the MC-TV isotropic branch used by prox_lmc_deconv.py:106-108 (``Op2 = Gradient``,
     ``isotropic=True``): value (algs.py:173-190) and gradient (algs.py:270-291,
-    ``grad = sigma Op^T(Op x - b) - lamda * Op2^T( Op2 x / max(|Op2 x|, gamma) )``), fused into the sampler step.
-    Not built: ME-TV (``Op2=None``, TV prox with niter_l2 = 50 inside the gradient, algs.py:282), anisotropic MC-TV
-    and the implicit ``prox`` (algs.py:201-267) -- they raise.
+    ``grad = sigma Op^T(Op x - b) - lamda * Op2^T( Op2 x / max(|Op2 x|, gamma) )``), fused into the sampler step, and the
+    implicit ``prox`` (algs.py:201-267; also inside ULPDA, prox_lmc_deconv.py:478-487).
+    Not built: ME-TV (``Op2=None``, TV prox with niter_l2 = 50 inside the gradient, algs.py:282) and anisotropic MC-TV
+    -- they raise.
     """
 
     def __init__(self, dims, Op=None, Op2=None, b=None, q=None, sigma=1., alpha=1., lamda=1., gamma=.5, qgrad=True,
@@ -350,4 +351,23 @@ class L2_ncvx_tv(ProxOperator):
         return self._problem().eval(x, 0.0, -1.0, 0.0, 0.0)
 
     def prox(self, x, tau):
-        raise NotImplementedError("L2_ncvx_tv.prox (algs.py:201-267, used by ULPDA with the non-convex term) is not built")
+        """``L2_ncvx_tv.prox`` (algs.py:201-267), MC-TV branch: ``v <- x + tau*lamda*Op2^T(Op2 x / max(|Op2 x|, gamma))`` then
+        ``(I + tau sigma Op^T Op)^{-1}(v + tau sigma Op^T b)`` by ``niter`` warm-started CG iterations (lmc_l2_prox).  Unlike
+        the reference (which adds the first term into its argument in place, :217) the input is left untouched."""
+        prob = self._problem()
+        n = self.dims[0] * self.dims[1]
+        xt = _dev.to_dev(x)
+        n_img = xt.numel() // n
+        lib = _dev.lib()
+        x0 = getattr(self, "_x0", None)
+        if self.warm and x0 is not None and x0.numel() == xt.numel():
+            out, warm = x0.clone(), 1
+        else:
+            out, warm = torch.empty_like(xt), 0
+        ws = torch.empty(lib.lmc_l2_prox_workspace_bytes(n_img, self.dims[0], self.dims[1]), dtype=torch.uint8, device=xt.device)
+        _capi.check(lib.lmc_l2_prox(C.byref(prob.c), _dev.ptr(xt), _dev.ptr(out), n_img, float(tau), int(self.niter), warm,
+                                    _dev.ptr(ws), _dev.stream_ptr()))
+        torch.cuda.current_stream().synchronize()
+        if self.warm:
+            self._x0 = out.clone()
+        return _dev.like_input(out.reshape(xt.shape), x)

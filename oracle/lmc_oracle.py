@@ -136,12 +136,41 @@ class _LinOp:
         return _Adjoint(self)
 
     def __mul__(self, x):
+        if isinstance(x, _LinOp):                # Op1 * Op2 (algs.py:248)
+            return _Product(self, x)
         return self.matvec(np.asarray(x).ravel())
 
     __matmul__ = __mul__
 
-    def __rmul__(self, a):                       # scalar * Op  (algs.py:159)
+    def __rmul__(self, a):                       # scalar * Op  (algs.py:159, 248)
         return _Scaled(self, a)
+
+    def __add__(self, other):                    # Op1 + Op2 (algs.py:247)
+        return _Sum(self, other)
+
+
+class _Product(_LinOp):
+    def __init__(self, a, b):
+        super().__init__((a.shape[0], b.shape[1]), a.dtype)
+        self.a, self.b = a, b
+
+    def matvec(self, x):
+        return self.a.matvec(self.b.matvec(x))
+
+    def rmatvec(self, y):
+        return self.b.rmatvec(self.a.rmatvec(y))
+
+
+class _Sum(_LinOp):
+    def __init__(self, a, b):
+        super().__init__(a.shape, a.dtype)
+        self.a, self.b = a, b
+
+    def matvec(self, x):
+        return self.a.matvec(x) + self.b.matvec(x)
+
+    def rmatvec(self, y):
+        return self.a.rmatvec(y) + self.b.rmatvec(y)
 
 
 class _Scaled(_LinOp):
@@ -516,6 +545,26 @@ class L2NcvxTV(_Prox):
     def grad(self, x):                                   # algs.py:283-291
         g = self.sigma * self.Op.rmatvec(self.Op.matvec(x) - self.b)
         return g - self.lamda * self.grad_moreau(x)
+
+    def prox(self, x, tau):
+        """Restatement of ``L2_ncvx_tv.prox`` (algs.py:201-267), MC-TV isotropic branch (:213-217) followed by the
+        linear solve (:224-256).  The reference solves ``(I + tau sigma Op^T Op) u = y`` with
+        ``scipy.sparse.linalg.lsqr(Op1, y, iter_lim=niter, x0=warm)``; here the same system goes through
+        :func:`cg_solve` (SPD system, condition number <= 1 + tau*sigma: both are converged to round-off after the
+        reference's 50 iterations -- checked against the reference's own output in tests/test_oracle_golden.py)."""
+        x = np.array(x, dtype=np.float64, copy=True)
+        if self.Op2 is None:
+            raise NotImplementedError("ME-TV prox branch not restated")
+        x = x + tau * self.lamda * self.grad_moreau(x)                       # algs.py:213-217
+        y = x + tau * self.sigma * self.Op.rmatvec(self.b)                   # algs.py:225 (OpTb = sigma Op^T b, :159)
+        ts = float(tau * self.sigma)
+
+        def apply_A(v):
+            return v + ts * self.Op.rmatvec(self.Op.matvec(v))
+        x0 = self._x0 if getattr(self, "_x0", None) is not None else np.zeros_like(y)
+        sol = cg_solve(apply_A, y, x0, self.niter)
+        self._x0 = sol                                                       # warm start (algs.py:255-256)
+        return sol
 
 
 # ----------------------------------------------------------------------------------

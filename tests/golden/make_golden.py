@@ -57,7 +57,9 @@ def install_standins():
         def __init__(self, Op=None, hasgrad=False):
             self.Op, self.hasgrad = Op, hasgrad
 
-    _mod("pylops", MatrixMult=None, Identity=None)
+    # Identity is only ever combined as Identity(n) + c * (Op.H * Op) and handed to scipy's lsqr (algs.py:247-251):
+    # the oracle's Identity operator carries that algebra (matvec / rmatvec / shape / dtype for scipy).
+    _mod("pylops", MatrixMult=None, Identity=lambda n, dtype=None: O.Identity(n))
     _mod("pylops.optimization")
     _mod("pylops.optimization.basic", lsqr=None)
     _mod("pylops.utils")
@@ -210,6 +212,20 @@ def gen_algs(out):
         d[f"{tag}_ncvx_x"] = xt
         d[f"{tag}_ncvx_mc_grad"], d[f"{tag}_ncvx_mc_val"] = mc.grad(xt.copy()), np.array(mc(xt.copy()))
         d[f"{tag}_ncvx_me_grad"], d[f"{tag}_ncvx_me_val"] = me.grad(xt.copy()), np.array(me(xt.copy()))
+        # L2_ncvx_tv.prox (algs.py:201-267): the reference's OWN code incl. its scipy.sparse.linalg.lsqr solve
+        # (iter_lim = niter = 50, warm start); prox mutates its argument in place (:217), hence the copies
+        rngp = np.random.default_rng(200 + seed)
+        vp = (img + rngp.normal(0, 5.0, img.shape)).ravel()
+        mcp = A.L2_ncvx_tv(dims=(ny, nx), Op=Hop, Op2=Gop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg,
+                           gamma=15.0, isotropic=True, niter=50, warm=True)
+        d[f"{tag}_ncvx_prox_in"] = vp
+        d[f"{tag}_ncvx_prox_out1"] = mcp.prox(vp.copy(), tau0)
+        d[f"{tag}_ncvx_prox_out2"] = mcp.prox((vp + 1.0).copy(), tau0)          # second call: warm-started
+        # ULPDA with the non-log-concave data term (prox_lmc_deconv.py:478-487 pattern: M2)
+        mcu = A.L2_ncvx_tv(dims=(ny, nx), Op=Hop, Op2=Gop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg,
+                           gamma=15.0, isotropic=True, niter=50, warm=True)
+        d[f"{tag}_ulpda_mc"] = A.UnadjustedLangevinPrimalDual(mcu, O.L21(ndim=2, sigma=tau_reg), Gop, tau=tau0, mu=mu0,
+                                                              theta=1.0, x0=x0, gfirst=False, niter=6, seed=seed)
         # MYULA with the non-log-concave data term (prox_lmc_deconv.py:492-501 pattern)
         d[f"{tag}_myula_mc_tv"] = A.MoreauYosidaUnadjustedLangevin(
             mc, O.TV((ny, nx), sigma=tau_reg, niter=10), tau=tau_myula, gamma=gamma_myula, x0=x0, niter=6, seed=seed)

@@ -86,3 +86,27 @@ def test_unbuilt_branches_raise(la):
         la.L2_ncvx_tv(dims=shape, Op=H, b=np.zeros(64), isotropic=True)                       # ME-TV
     with pytest.raises(NotImplementedError):
         la.L2_ncvx_tv(dims=shape, Op=H, Op2=la.Gradient(shape), b=np.zeros(64), isotropic=False)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_ncvx_prox_and_ulpda_match_reference(la, golden, tag):
+    """L2_ncvx_tv.prox and ULPDA with the non-log-concave data term (prox_lmc_deconv.py:478-487) against outputs of the
+    reference's own class incl. its scipy LSQR solve (which stops at ~1e-6 relative residual: tolerance 1e-4)."""
+    g = golden("algs.npz")
+    sigma, tau_reg, tau_myula, gamma_myula, tau0, mu0 = [float(v) for v in g["params"]]
+    ny, nx, k, seed = [int(v) for v in g[f"{tag}_meta"]]
+    h, y = g[f"{tag}_h"], g[f"{tag}_y"]
+    H = la.Convolve2D((ny, nx), h, offset=(k // 2, k // 2))
+    G = la.Gradient((ny, nx))
+    mk = lambda: la.L2_ncvx_tv(dims=(ny, nx), Op=H, Op2=G, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=15.0,
+                               isotropic=True, niter=50, warm=True)
+    mc = mk()
+    vp = g[f"{tag}_ncvx_prox_in"]
+    keep = vp.copy()
+    assert rel(mc.prox(vp, tau0), g[f"{tag}_ncvx_prox_out1"]) < 1e-4
+    np.testing.assert_array_equal(vp, keep)                     # input untouched
+    assert rel(mc.prox(vp + 1.0, tau0), g[f"{tag}_ncvx_prox_out2"]) < 1e-4
+    gx = g[f"{tag}_ulpda_mc"]
+    xs = la.UnadjustedLangevinPrimalDual(mk(), la.L21(ndim=2, sigma=tau_reg), G, tau=tau0, mu=mu0, theta=1.0,
+                                         x0=np.zeros(ny * nx), gfirst=False, niter=gx.shape[0], seed=seed, rng="pcg64")
+    assert rel(xs, gx) < 2e-4, rel(xs, gx)
