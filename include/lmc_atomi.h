@@ -59,7 +59,9 @@ typedef enum lmc_prior_kind {
 
 typedef enum lmc_ncvx_kind {
   LMC_NCVX_NONE = 0,
-  LMC_NCVX_MC_TV = 1    /* minimax-concave TV (Moreau envelope of l1 composed with the gradient), isotropic */
+  LMC_NCVX_MC_TV = 1,   /* minimax-concave TV (Moreau envelope of l1 composed with the gradient), isotropic */
+  LMC_NCVX_ME_TV = 2    /* Moreau envelope of isotropic TV itself (Op2 = None): grad env = (x - prox_{gamma TV}(x))/gamma,
+                         * prox by ncvx_niter FGP iterations (niter_l2 = 50 at prox_lmc_deconv.py:111; algs.py:169,282) */
 } lmc_ncvx_kind;
 
 typedef enum lmc_noise_mode {
@@ -92,7 +94,8 @@ typedef struct lmc_problem {
    * LMC_NCVX_MC_TV: Op2 = gradient, isotropic (algs.py:273-277): grad f = sigma_f H^T(Hx-y) - lambda * A^T( A x / max(|A x|, gamma) ) */
   int32_t ncvx_kind;        /* lmc_ncvx_kind */
   float ncvx_lambda;        /* lamda (= tau_reg at prox_lmc_deconv.py:106) */
-  float ncvx_gamma;         /* gamma (= gamma_mc = 15 at prox_lmc_deconv.py:40,106) */
+  float ncvx_gamma;         /* gamma (= gamma_mc = gamma_me = 15 at prox_lmc_deconv.py:40,106,111) */
+  int32_t ncvx_niter;       /* LMC_NCVX_ME_TV: dual iterations of the inner TV prox */
 } lmc_problem;
 
 /* ---- library ------------------------------------------------------------------------- */

@@ -17,7 +17,7 @@ ABI_VERSION = 1
 DATA_NONE, DATA_IDENTITY, DATA_BLUR, DATA_MASK = 0, 1, 2, 3
 PRIOR_NONE, PRIOR_L2, PRIOR_L1, PRIOR_TV_ISO, PRIOR_TV_ANISO = 0, 1, 2, 3, 4
 NOISE_PHILOX, NOISE_INJECTED, NOISE_NONE = 0, 1, 2
-NCVX_NONE, NCVX_MC_TV = 0, 1
+NCVX_NONE, NCVX_MC_TV, NCVX_ME_TV = 0, 1, 2
 MAX_BLUR = 9
 MAX_TV_ITERS = 64
 (EPROX_LAPLACE, EPROX_UNCENTERED_LAPLACE, EPROX_GAUSSIAN, EPROX_GEN_GAUSSIAN_4_3, EPROX_GEN_GAUSSIAN_3_2,
@@ -51,6 +51,7 @@ class lmc_problem(C.Structure):
         ("ncvx_kind", C.c_int32),
         ("ncvx_lambda", C.c_float),
         ("ncvx_gamma", C.c_float),
+        ("ncvx_niter", C.c_int32),
     ]
 
 

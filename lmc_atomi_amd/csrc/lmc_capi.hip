@@ -68,7 +68,49 @@ struct Problem {
   float betas[lmc::kMaxTvIters] = {};
   int ncvx_kind = 0;
   float ncvx_lambda = 0.f, ncvx_gamma = 1.f;
+  int ncvx_niter = 0;
 };
+
+// Device scratch for the stateless entry points (grown on demand, kept for the life of the process; calls are
+// serialised by the caller, see lmc_atomi.h).  Samplers own their buffers instead.
+struct Scratch {
+  float* state[2] = {nullptr, nullptr};   // TV dual state ping-pong, [n][4][H][W] each
+  float* extra = nullptr;                 // ME-TV inner prox, [n][H][W]
+  double* dbl = nullptr;                  // 2*n doubles
+  size_t n_state = 0, n_extra = 0, n_dbl = 0;
+  hipError_t need_state(size_t n) {
+    if (n <= n_state) return hipSuccess;
+    for (float*& p : state) { if (p) (void)hipFree(p); p = nullptr; }
+    n_state = 0;
+    hipError_t e = hipMalloc(&state[0], sizeof(float) * n);
+    if (e == hipSuccess) e = hipMalloc(&state[1], sizeof(float) * n);
+    if (e == hipSuccess) n_state = n;
+    return e;
+  }
+  hipError_t need_extra(size_t n) {
+    if (n <= n_extra) return hipSuccess;
+    if (extra) (void)hipFree(extra);
+    extra = nullptr; n_extra = 0;
+    hipError_t e = hipMalloc(&extra, sizeof(float) * n);
+    if (e == hipSuccess) n_extra = n;
+    return e;
+  }
+  hipError_t need_dbl(size_t n) {
+    if (n <= n_dbl) return hipSuccess;
+    if (dbl) (void)hipFree(dbl);
+    dbl = nullptr; n_dbl = 0;
+    hipError_t e = hipMalloc(&dbl, sizeof(double) * n);
+    if (e == hipSuccess) n_dbl = n;
+    return e;
+  }
+  void release() {
+    for (float*& p : state) { if (p) (void)hipFree(p); p = nullptr; }
+    if (extra) (void)hipFree(extra);
+    if (dbl) (void)hipFree(dbl);
+    extra = nullptr; dbl = nullptr; n_state = n_extra = n_dbl = 0;
+  }
+};
+Scratch g_scratch;
 
 int load_problem(const lmc_problem* p, Problem& q) {
   if (!p) return fail(LMC_E_INVALID, "lmc_problem is NULL");
@@ -112,9 +154,11 @@ int load_problem(const lmc_problem* p, Problem& q) {
   }
   if (p->prior_kind != LMC_PRIOR_NONE && !(p->prior_sigma >= 0.f)) return fail(LMC_E_INVALID, "prior_sigma must be >= 0");
   if (p->ncvx_kind != LMC_NCVX_NONE) {
-    if (p->ncvx_kind != LMC_NCVX_MC_TV) return fail(LMC_E_UNSUPPORTED, "unknown ncvx_kind %d (only LMC_NCVX_MC_TV is built)", p->ncvx_kind);
+    if (p->ncvx_kind != LMC_NCVX_MC_TV && p->ncvx_kind != LMC_NCVX_ME_TV) return fail(LMC_E_INVALID, "unknown ncvx_kind %d", p->ncvx_kind);
     if (!(p->ncvx_gamma > 0.f)) return fail(LMC_E_INVALID, "ncvx_gamma must be > 0");
-    q.ncvx_kind = p->ncvx_kind; q.ncvx_lambda = p->ncvx_lambda; q.ncvx_gamma = p->ncvx_gamma;
+    if (p->ncvx_kind == LMC_NCVX_ME_TV && (p->ncvx_niter < 1 || p->ncvx_niter > lmc::kMaxTvIters))
+      return fail(LMC_E_INVALID, "ncvx_niter %d outside 1..%d", p->ncvx_niter, lmc::kMaxTvIters);
+    q.ncvx_kind = p->ncvx_kind; q.ncvx_lambda = p->ncvx_lambda; q.ncvx_gamma = p->ncvx_gamma; q.ncvx_niter = p->ncvx_niter;
   }
   return LMC_OK;
 }
@@ -138,9 +182,10 @@ int make_step_args(const Problem& q, float a, float t, float b, float pt, float 
     A.tv.c = q.tv_step / gam;
     std::memcpy(A.tv.betas, q.betas, sizeof(float) * q.tv_niter);
   }
-  if (t != 0.f && q.ncvx_kind != LMC_NCVX_NONE) {
+  if (t != 0.f && q.ncvx_kind == LMC_NCVX_MC_TV) {
     A.ncvx_kind = q.ncvx_kind; A.ncvx_lambda = q.ncvx_lambda; A.ncvx_gamma = q.ncvx_gamma; A.ncvx_inv_gamma = 1.f / q.ncvx_gamma;
   }
+  // LMC_NCVX_ME_TV: the caller runs me_tv_prox first and sets A.extra / A.extra_coef
   A.a = a; A.t = t; A.b = b; A.s = s;
   A.noise_mode = LMC_NOISE_NONE;
   return LMC_OK;
@@ -158,7 +203,8 @@ int g_variant = 0;  // 0 auto, 1 tile, 2 stream, 3 split, 4 point
 
 // Picks the step-kernel variant.  auto: the split streaming pipeline (two wave groups, 4 waves/SIMD) when
 // it covers the configuration (W <= 512, separable blur <= 7x7, supported K), else the LDS-tiled kernel.
-hipError_t launch_step(const lmc::StepArgs& A, hipStream_t st, const char** name) {
+hipError_t launch_step(const lmc::StepArgs& A, hipStream_t st, const char** name, float* state0 = nullptr,
+                       float* state1 = nullptr) {
   int v = g_variant;
   // auto: split pipeline when it covers the configuration (W <= 512); for wider images the tiled kernels:
   // "point" for closed-form priors with a separable blur, else the general LDS-tiled kernel
@@ -179,7 +225,36 @@ hipError_t launch_step(const lmc::StepArgs& A, hipStream_t st, const char** name
     return lmc::launch_step_stream(A, st);
   }
   if (name) *name = "myula_step_tile_kernel";
+  if (lmc::tile_needs_chunks(A)) {
+    if (!state0 || !state1) return hipErrorInvalidConfiguration;
+    return lmc::launch_step_tile_chunked(A, state0, state1, st);
+  }
   return lmc::launch_step_tile(A, st);
+}
+
+bool needs_tv_state(const Problem& q) {
+  return (q.prior_kind == LMC_PRIOR_TV_ISO && q.tv_niter > 12) || (q.ncvx_kind == LMC_NCVX_ME_TV && q.ncvx_niter > 12);
+}
+
+// extra <- prox_{gamma TV}(x) with ncvx_niter dual iterations (the inner prox of the ME-TV term, algs.py:169,282)
+int me_tv_prox(const Problem& q, const float* x, float* extra, int64_t n_img, float* state0, float* state1, hipStream_t st) {
+  lmc::StepArgs A;
+  std::memset(&A, 0, sizeof A);
+  A.H = q.H; A.W = q.W; A.C = (int)n_img;
+  A.data_kind = LMC_DATA_NONE;
+  A.prior_kind = LMC_PRIOR_TV_ISO;
+  A.tv.niter = q.ncvx_niter;
+  A.tv.gamma = q.ncvx_gamma;          // g_gamma = TV(dims, sigma = 1) evaluated at prox parameter gamma (algs.py:169,282)
+  A.tv.c = 0.125f / q.ncvx_gamma;
+  default_betas(A.tv.betas, q.ncvx_niter);
+  A.a = 0.f; A.t = 0.f; A.b = 1.f; A.s = 0.f;
+  A.noise_mode = LMC_NOISE_NONE;
+  A.x_in = x; A.x_out = extra;
+  A.y = x; A.mask = x; A.noise = x;
+  hipError_t e = launch_step(A, st, nullptr, state0, state1);
+  if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no kernel covers the inner TV prox of the ME-TV term");
+  HIP_TRY(e);
+  return LMC_OK;
 }
 
 }  // namespace
@@ -193,6 +268,8 @@ struct lmc_sampler {
   float* xhat = nullptr; float* ydual = nullptr; float* uw = nullptr; float* rhs = nullptr;
   float* cr = nullptr; float* cp = nullptr; float* cq = nullptr; float* ctmp = nullptr; float* xi = nullptr;
   float* htb = nullptr; double* scal = nullptr;
+  float* tvstate[2] = {nullptr, nullptr};   // dual-state ping-pong for chunked TV proxes (K > 12, ME-TV)
+  float* extra = nullptr;                   // ME-TV inner prox
   Problem prob;
   int C = 0;
   int64_t chain_offset = 0;
@@ -272,7 +349,16 @@ int lmc_fused_eval(const lmc_problem* prob, const float* x_dev, float* out_dev, 
   A.x_in = x_dev;
   A.x_out = out_dev;
   sanitize_pointers(A);
-  hipError_t e = launch_step(A, S(stream), nullptr);
+  const size_t npx = (size_t)n_img * q.H * q.W;
+  if (needs_tv_state(q)) HIP_TRY(g_scratch.need_state(4 * npx));
+  if (t != 0.f && q.ncvx_kind == LMC_NCVX_ME_TV) {
+    HIP_TRY(g_scratch.need_extra(npx));
+    rc = me_tv_prox(q, x_dev, g_scratch.extra, n_img, g_scratch.state[0], g_scratch.state[1], S(stream));
+    if (rc) return rc;
+    A.extra = g_scratch.extra;
+    A.extra_coef = -q.ncvx_lambda / q.ncvx_gamma;
+  }
+  hipError_t e = launch_step(A, S(stream), nullptr, g_scratch.state[0], g_scratch.state[1]);
   if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no step-kernel variant covers this configuration");
   HIP_TRY(e);
   return LMC_OK;
@@ -282,8 +368,23 @@ static lmc::EnergyArgs energy_args(const Problem& q) {
   lmc::EnergyArgs E;
   E.H = q.H; E.W = q.W; E.data_kind = q.data_kind; E.sigma_f = q.sigma_f; E.y = q.y; E.mask = q.mask;
   E.blur = q.taps; E.prior_kind = q.prior_kind; E.prior_sigma = q.prior_sigma;
-  E.ncvx_kind = q.ncvx_kind; E.ncvx_lambda = q.ncvx_lambda; E.ncvx_gamma = q.ncvx_gamma;
+  E.ncvx_kind = q.ncvx_kind == LMC_NCVX_MC_TV ? LMC_NCVX_MC_TV : LMC_NCVX_NONE;   // ME-TV envelope: me_tv_energy
+  E.ncvx_lambda = q.ncvx_lambda; E.ncvx_gamma = q.ncvx_gamma;
   return E;
+}
+
+// f_out -= lambda * ( TV(prox) + ||x - prox||^2 / (2 gamma) ),  prox = prox_{gamma TV}(x)    (algs.py:178-190, ME-TV)
+static int me_tv_energy(const Problem& q, const float* x, int64_t n_img, double* f_out, float* extra, float* st0, float* st1,
+                        double* dbl /* 2*n_img */, hipStream_t st) {
+  int rc = me_tv_prox(q, x, extra, n_img, st0, st1, st);
+  if (rc) return rc;
+  lmc::EnergyArgs E;
+  std::memset(&E, 0, sizeof E);
+  E.H = q.H; E.W = q.W; E.data_kind = LMC_DATA_NONE; E.prior_kind = LMC_PRIOR_TV_ISO; E.prior_sigma = 1.f;
+  HIP_TRY(lmc::launch_energies(extra, n_img, E, nullptr, dbl, st));                       // TV(prox)
+  HIP_TRY(lmc::launch_sqdiff(x, extra, n_img, (size_t)q.H * q.W, dbl + n_img, st));      // ||x - prox||^2
+  HIP_TRY(lmc::launch_axpy_env(f_out, dbl, dbl + n_img, n_img, q.ncvx_lambda, q.ncvx_gamma, st));
+  return LMC_OK;
 }
 
 int lmc_energies(const lmc_problem* prob, const float* x_dev, int64_t n_img, double* f_out_dev, double* g_out_dev,
@@ -293,6 +394,14 @@ int lmc_energies(const lmc_problem* prob, const float* x_dev, int64_t n_img, dou
   if (rc) return rc;
   if (!x_dev || n_img < 1) return fail(LMC_E_INVALID, "bad arguments");
   HIP_TRY(lmc::launch_energies(x_dev, n_img, energy_args(q), f_out_dev, g_out_dev, S(stream)));
+  if (q.ncvx_kind == LMC_NCVX_ME_TV && f_out_dev) {
+    const size_t npx = (size_t)n_img * q.H * q.W;
+    HIP_TRY(g_scratch.need_state(4 * npx));
+    HIP_TRY(g_scratch.need_extra(npx));
+    HIP_TRY(g_scratch.need_dbl(2 * (size_t)n_img));
+    rc = me_tv_energy(q, x_dev, n_img, f_out_dev, g_scratch.extra, g_scratch.state[0], g_scratch.state[1], g_scratch.dbl, S(stream));
+    if (rc) return rc;
+  }
   return LMC_OK;
 }
 
@@ -391,6 +500,11 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
   hipError_t e = hipMalloc(&s->x[0], nbytes);
   if (e == hipSuccess) e = hipMalloc(&s->x[1], nbytes);
   if (e == hipSuccess) e = hipMemset(s->x[0], 0, nbytes);
+  if (e == hipSuccess && needs_tv_state(s->prob)) {
+    e = hipMalloc(&s->tvstate[0], 4 * nbytes);
+    if (e == hipSuccess) e = hipMalloc(&s->tvstate[1], 4 * nbytes);
+  }
+  if (e == hipSuccess && s->prob.ncvx_kind == LMC_NCVX_ME_TV) e = hipMalloc(&s->extra, nbytes);
   if (e == hipSuccess && s->moments) {
     const size_t mb = sizeof(double) * (size_t)s->prob.H * s->prob.W;
     e = hipMalloc(&s->s1, mb);
@@ -410,7 +524,7 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
 
 void lmc_sampler_destroy(lmc_sampler* s) {
   if (!s) return;
-  for (float* b : {s->xhat, s->ydual, s->uw, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb})
+  for (float* b : {s->xhat, s->ydual, s->uw, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra})
     if (b) (void)hipFree(b);
   if (s->scal) (void)hipFree(s->scal);
   if (s->x[0]) (void)hipFree(s->x[0]);
@@ -473,9 +587,15 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     A.iteration = (uint32_t)s->iteration;
     A.noise = noise_dev ? noise_dev + (size_t)k * per_iter : nullptr;
     sanitize_pointers(A);
+    if (s->prob.ncvx_kind == LMC_NCVX_ME_TV) {   // inner prox of the Moreau-envelope term, then the fused step
+      int rc = me_tv_prox(s->prob, A.x_in, s->extra, s->C, s->tvstate[0], s->tvstate[1], st);
+      if (rc) return rc;
+      A.extra = s->extra;
+      A.extra_coef = -s->prob.ncvx_lambda / s->prob.ncvx_gamma;
+    }
     if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * k], st));
     const char* kname = nullptr;
-    hipError_t e = launch_step(A, st, &kname);
+    hipError_t e = launch_step(A, st, &kname, s->tvstate[0], s->tvstate[1]);
     if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no step-kernel variant covers this configuration");
     HIP_TRY(e);
     if (kname) s->kernel_name = kname;
@@ -563,6 +683,8 @@ int lmc_ulpda_create(const lmc_ulpda_config* cfg, lmc_sampler** out) {
     return fail(LMC_E_UNSUPPORTED, "ULPDA needs g o A with g = L21 (LMC_PRIOR_TV_ISO) or L1 (LMC_PRIOR_TV_ANISO)");
   if (!(cfg->problem.prior_sigma > 0.f)) return fail(LMC_E_INVALID, "prior_sigma (dual ball radius) must be > 0");
   if (cfg->problem.data_kind == LMC_DATA_BLUR && cfg->cg_niter < 1) return fail(LMC_E_INVALID, "cg_niter must be >= 1");
+  if (cfg->problem.ncvx_kind == LMC_NCVX_ME_TV)
+    return fail(LMC_E_UNSUPPORTED, "ULPDA with the ME-TV data term (L2_ncvx_tv.prox, algs.py:221-223) is not built");
   if (cfg->problem.ncvx_kind != LMC_NCVX_NONE && cfg->problem.data_kind != LMC_DATA_BLUR)
     return fail(LMC_E_UNSUPPORTED, "the non-convex term is built for the blur data term only (prox_lmc_deconv.py:106)");
   lmc_sampler* s = new (std::nothrow) lmc_sampler();
@@ -665,6 +787,11 @@ int lmc_sampler_reset_moments(lmc_sampler* s, void* stream) {
 int lmc_sampler_energies(lmc_sampler* s, double* f_out_dev, double* g_out_dev, void* stream) {
   if (!s) return fail(LMC_E_INVALID, "NULL sampler");
   HIP_TRY(lmc::launch_energies(s->x[s->cur], s->C, energy_args(s->prob), f_out_dev, g_out_dev, S(stream)));
+  if (s->prob.ncvx_kind == LMC_NCVX_ME_TV && f_out_dev) {
+    HIP_TRY(g_scratch.need_dbl(2 * (size_t)s->C));
+    int rc = me_tv_energy(s->prob, s->x[s->cur], s->C, f_out_dev, s->extra, s->tvstate[0], s->tvstate[1], g_scratch.dbl, S(stream));
+    if (rc) return rc;
+  }
   return LMC_OK;
 }
 

@@ -45,6 +45,14 @@ struct StepArgs {
   uint32_t chain_offset;     // global id of chain 0 (counter word 2 = chain_offset + c)
   const float* x_in;
   float* x_out;
+  // resumable TV prox (tile kernel): dual state [C][4][H][W] = (rr, ss, p, q) carried between launches so that
+  // more dual iterations than one launch's halo allows can be chained exactly; tv.betas is already offset.
+  const float* tv_in;        // NULL: start from zero
+  float* tv_out;             // NULL: do not store
+  int tv_state_only;         // != 0: store the state and skip the combine / x_out (non-final chunk)
+  // extra gradient term g += extra_coef * (x - extra[c][i][j])   (ME-TV: extra = prox_{gamma TV}(x), algs.py:282)
+  const float* extra;
+  float extra_coef;
 };
 
 constexpr uint32_t kPhiloxStream = 0x4C4D4301u;  // counter word 3

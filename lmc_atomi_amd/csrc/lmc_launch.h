@@ -18,6 +18,10 @@ struct EnergyArgs {
 };
 
 hipError_t launch_step_tile(StepArgs a, hipStream_t st);
+bool tile_needs_chunks(const StepArgs& a);
+hipError_t launch_step_tile_chunked(const StepArgs& a, float* state0, float* state1, hipStream_t st);
+hipError_t launch_axpy_env(double* f, const double* tvv, const double* sq, int64_t n, float lambda, float gamma, hipStream_t st);
+hipError_t launch_sqdiff(const float* a, const float* b, int64_t n_img, size_t img, double* out, hipStream_t st);
 hipError_t launch_blur(const float* x, float* out, int64_t n_img, int H, int W, const BlurTaps& T, int adjoint,
                        hipStream_t st);
 hipError_t launch_gradient(const float* x, float* out, int64_t n_img, int H, int W, bool adjoint, hipStream_t st);

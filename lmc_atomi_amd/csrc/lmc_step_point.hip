@@ -156,6 +156,7 @@ __global__ __launch_bounds__(kPtThreads) void myula_step_point_kernel(const Step
         g -= P.ncvx_lambda * mc_tv_grad(xs[(r - 1) * PW + c], xs[(r - 1) * PW + c + 1], xs[r * PW + c - 1], x, xs[r * PW + c + 1],
                                         xs[(r + 1) * PW + c - 1], xs[(r + 1) * PW + c], gr > 0, gr + 1 < H, gc > 0, gc + 1 < W,
                                         P.ncvx_gamma);
+      if (P.extra) g = fmaf(P.extra_coef, x - P.extra[(size_t)chain * img + gi], g);
       float px = x;
       if (P.prior_kind == LMC_PRIOR_L2) px = x * P.prior_p0;
       else if (P.prior_kind == LMC_PRIOR_L1) px = copysignf(fmaxf(fabsf(x) - P.prior_p0, 0.f), x);

@@ -339,6 +339,7 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
       g -= A.ncvx_lambda * mc_tv_grad(xm[0], xm[1], x0[-1], x, x0[1], xp[-1], xp[0], o > 0, o + 1 < H, c.col > 0,
                                       c.col + 1 < W, A.ncvx_gamma);
     }
+    if (A.extra) g = fmaf(A.extra_coef, x - A.extra[(size_t)c.chain * H * W + gi], g);   // ME-TV term (algs.py:282)
     float px;
     if (K > 0) {
       px = prox_o;

@@ -111,6 +111,20 @@ __global__ __launch_bounds__(kStepThreads) void myula_step_tile_kernel(const Ste
     float rrv[NP], ssv[NP], pv[NP], qv[NP], solv[NP];
 #pragma unroll
     for (int m = 0; m < NP; ++m) { rrv[m] = ssv[m] = pv[m] = qv[m] = 0.f; }
+    if (P.tv_in) {   // resume: dual state of the previous launch (tile + halo), zero outside the image
+      const float* __restrict__ st = P.tv_in + (size_t)chain * 4 * img;
+#pragma unroll
+      for (int m = 0; m < NP; ++m) {
+        const int p = tid + m * kStepThreads;
+        if (p < npix && (flags[m] & 1)) {
+          const int r = p / PW, c = p - r * PW;
+          const size_t gi = (size_t)(row0 + r) * W + (col0 + c);
+          rrv[m] = st[gi]; ssv[m] = st[img + gi]; pv[m] = st[2 * img + gi]; qv[m] = st[3 * img + gi];
+          A[p] = rrv[m]; B[p] = ssv[m];
+        }
+      }
+      __syncthreads();
+    }
     const float gam = P.tv.gamma, cstep = P.tv.c;
     for (int k = 0; k <= P.tv.niter; ++k) {
       // A-phase: sol = x - gamma * div(rr, ss)
@@ -147,7 +161,22 @@ __global__ __launch_bounds__(kStepThreads) void myula_step_tile_kernel(const Ste
       }
       __syncthreads();
     }
+    if (P.tv_out) {   // store the dual state of the tile interior for the next launch
+      float* __restrict__ st = P.tv_out + (size_t)chain * 4 * img;
+#pragma unroll
+      for (int m = 0; m < NP; ++m) {
+        const int p = tid + m * kStepThreads;
+        if (p < npix && (flags[m] & 1)) {
+          const int r = p / PW, c = p - r * PW;
+          if (r >= HL && r < HL + P.TH && c >= HL && c < HL + P.TW) {
+            const size_t gi = (size_t)(row0 + r) * W + (col0 + c);
+            st[gi] = rrv[m]; st[img + gi] = ssv[m]; st[2 * img + gi] = pv[m]; st[3 * img + gi] = qv[m];
+          }
+        }
+      }
+    }
   }
+  if (P.tv_state_only) return;
 
   // ---- phase 4: combine + noise + store ----------------------------------------------------
   if (!own_int) return;
@@ -179,6 +208,7 @@ __global__ __launch_bounds__(kStepThreads) void myula_step_tile_kernel(const Ste
       g -= P.ncvx_lambda * mc_tv_grad(xs[p - PW], xs[p - PW + 1], xs[p - 1], x, xs[p + 1], xs[p + PW - 1], xs[p + PW],
                                       gr > 0, gr + 1 < H, gc > 0, gc + 1 < W, P.ncvx_gamma);
     }
+    if (P.extra) g = fmaf(P.extra_coef, x - P.extra[(size_t)chain * img + gi], g);   // ME-TV: -lambda/gamma (x - prox_{gamma TV}(x))
     float px;
     if (TV) {
       px = S[p];
@@ -263,6 +293,69 @@ hipError_t launch_step_tile(StepArgs a, hipStream_t st) {
   a.tiles_x = (a.W + tp.TW - 1) / tp.TW;
   a.tiles_y = (a.H + tp.TH - 1) / tp.TH;
   return tv ? launch_tv<true>(a, tp.NP, tp.lds_bytes, st) : launch_tv<false>(a, tp.NP, tp.lds_bytes, st);
+}
+
+
+// TV prox with more dual iterations than one launch's halo allows: chunks of <= kTvChunk iterations chained exactly
+// through the dual state (rr, ss, p, q) in HBM (two ping-pong buffers of [C][4][H][W] floats each).  Non-final chunks
+// only advance the state; the final chunk also does the blur gradient, the combine and the store.
+constexpr int kTvChunk = 8;
+
+bool tile_needs_chunks(const StepArgs& a) {
+  return a.prior_kind == LMC_PRIOR_TV_ISO && a.tv.niter > 12;
+}
+
+hipError_t launch_step_tile_chunked(const StepArgs& a, float* state0, float* state1, hipStream_t st) {
+  const int K = a.tv.niter;
+  const int n_chunks = (K + kTvChunk - 1) / kTvChunk;
+  float* state[2] = {state0, state1};
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const int k0 = ch * kTvChunk, kn = (K - k0 < kTvChunk) ? K - k0 : kTvChunk;
+    const bool last = ch == n_chunks - 1;
+    StepArgs b = a;
+    b.tv.niter = kn;
+    for (int i = 0; i < kn; ++i) b.tv.betas[i] = a.tv.betas[k0 + i];
+    b.tv_in = ch > 0 ? state[(ch - 1) & 1] : nullptr;
+    b.tv_out = last ? nullptr : state[ch & 1];
+    b.tv_state_only = last ? 0 : 1;
+    if (!last) { b.data_kind = LMC_DATA_NONE; b.ncvx_kind = LMC_NCVX_NONE; b.extra = nullptr; }
+    hipError_t e = launch_step_tile(b, st);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// per-image sum of squared differences ||a_i - b_i||^2 (ME-TV envelope value), one atomic per block
+__global__ __launch_bounds__(256) void sqdiff_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t img,
+                                                     double* __restrict__ out) {
+  __shared__ double scratch[4];
+  const size_t c = blockIdx.y;
+  double acc = 0.0;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.x * blockDim.x) {
+    const double d = (double)a[c * img + k] - (double)b[c * img + k];
+    acc += d * d;
+  }
+  const double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) unsafeAtomicAdd(&out[c], t);
+}
+
+__global__ void axpy_env_kernel(double* f, const double* tvv, const double* sq, int64_t n, float lambda, float gamma) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) f[i] -= (double)lambda * (tvv[i] + sq[i] / (2.0 * (double)gamma));
+}
+
+hipError_t launch_axpy_env(double* f, const double* tvv, const double* sq, int64_t n, float lambda, float gamma, hipStream_t st) {
+  hipLaunchKernelGGL(axpy_env_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f, tvv, sq, n, lambda, gamma);
+  return hipGetLastError();
+}
+
+hipError_t launch_sqdiff(const float* a, const float* b, int64_t n_img, size_t img, double* out, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(double) * n_img, st);
+  if (e != hipSuccess) return e;
+  int gx = (int)((img + 255) / 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(sqdiff_kernel, dim3(gx, (unsigned)n_img), dim3(256), 0, st, a, b, img, out);
+  return hipGetLastError();
 }
 
 }  // namespace lmc

@@ -92,6 +92,7 @@ class _Problem:
         p.ncvx_kind = int(data.get("ncvx_kind", _capi.NCVX_NONE))
         p.ncvx_lambda = float(data.get("ncvx_lambda", 0.0))
         p.ncvx_gamma = float(data.get("ncvx_gamma", 1.0))
+        p.ncvx_niter = int(data.get("ncvx_niter", 0))
         self.c = p
 
     def eval(self, x, a, t, b, pt):
@@ -305,12 +306,13 @@ class L2_ncvx_tv(ProxOperator):
     r"""Non-log-concave data term -- drop-in for the reference's own class ``algs.L2_ncvx_tv`` (algs.py:22-291):
     ``f(x) = sigma/2 ||Op x - b||^2 - lamda * env_gamma(g)(Op2 x)``, same constructor arguments.
 
-    Built on the GPU: the MC-TV isotropic branch used by prox_lmc_deconv.py:106-108 (``Op2 = Gradient``,
-    ``isotropic=True``): value (algs.py:173-190) and gradient (algs.py:270-291,
-    ``grad = sigma Op^T(Op x - b) - lamda * Op2^T( Op2 x / max(|Op2 x|, gamma) )``), fused into the sampler step, and the
-    implicit ``prox`` (algs.py:201-267; also inside ULPDA, prox_lmc_deconv.py:478-487).
-    Not built: ME-TV (``Op2=None``, TV prox with niter_l2 = 50 inside the gradient, algs.py:282) and anisotropic MC-TV
-    -- they raise.
+    Built on the GPU, both isotropic branches used by prox_lmc_deconv.py:106-113:
+    * MC-TV (``Op2 = Gradient``): value (algs.py:173-190), gradient (:270-291,
+      ``sigma Op^T(Op x - b) - lamda * Op2^T( Op2 x / max(|Op2 x|, gamma) )``) fused into the sampler step, and the implicit
+      ``prox`` (:201-267; also inside ULPDA, prox_lmc_deconv.py:478-487);
+    * ME-TV (``Op2 = None``): value and gradient ``sigma Op^T(Op x - b) - lamda (x - prox_{gamma TV}(x))/gamma`` (:282), the inner
+      TV prox with ``niter`` (= niter_l2 = 50) dual iterations chained exactly through HBM-resident dual state in chunks of 8.
+    Not built: anisotropic variants, ``prox`` of the ME-TV term -- they raise.
     """
 
     def __init__(self, dims, Op=None, Op2=None, b=None, q=None, sigma=1., alpha=1., lamda=1., gamma=.5, qgrad=True,
@@ -319,10 +321,10 @@ class L2_ncvx_tv(ProxOperator):
         from .operators import Gradient
         if q is not None:
             raise NotImplementedError("q (linear term) has no device functor")
-        if Op2 is None:
-            raise NotImplementedError("ME-TV (Op2=None): TV prox inside the gradient is not built on the GPU yet")
-        if not isinstance(Op2, Gradient) or not isotropic:
-            raise NotImplementedError("only the isotropic MC-TV branch (Op2=Gradient, isotropic=True) is built")
+        if not isotropic:
+            raise NotImplementedError("only the isotropic branches (isotropic=True, as at prox_lmc_deconv.py:106-113) are built")
+        if Op2 is not None and not isinstance(Op2, Gradient):
+            raise NotImplementedError("Op2 must be a Gradient (MC-TV) or None (ME-TV)")
         if not isinstance(Op, Convolve2D) or b is None:
             raise NotImplementedError("Op must be a Convolve2D and b given (prox_lmc_deconv.py:106)")
         self.dims = (int(dims[0]), int(dims[1]))
@@ -336,7 +338,8 @@ class L2_ncvx_tv(ProxOperator):
 
     def descriptor(self):
         return {"data_kind": _capi.DATA_BLUR, "sigma_f": self.sigma, "y": self.b, "h": self.Op.h, "offset": self.Op.offset,
-                "ncvx_kind": _capi.NCVX_MC_TV, "ncvx_lambda": self.lamda, "ncvx_gamma": self.gamma}
+                "ncvx_kind": _capi.NCVX_MC_TV if self.Op2 is not None else _capi.NCVX_ME_TV,
+                "ncvx_lambda": self.lamda, "ncvx_gamma": self.gamma, "ncvx_niter": int(self.niter)}
 
     def _problem(self):
         if self._prob is None:
@@ -354,6 +357,8 @@ class L2_ncvx_tv(ProxOperator):
         """``L2_ncvx_tv.prox`` (algs.py:201-267), MC-TV branch: ``v <- x + tau*lamda*Op2^T(Op2 x / max(|Op2 x|, gamma))`` then
         ``(I + tau sigma Op^T Op)^{-1}(v + tau sigma Op^T b)`` by ``niter`` warm-started CG iterations (lmc_l2_prox).  Unlike
         the reference (which adds the first term into its argument in place, :217) the input is left untouched."""
+        if self.Op2 is None:
+            raise NotImplementedError("L2_ncvx_tv.prox for ME-TV (algs.py:221-223) is not built")
         prob = self._problem()
         n = self.dims[0] * self.dims[1]
         xt = _dev.to_dev(x)

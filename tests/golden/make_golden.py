@@ -226,6 +226,11 @@ def gen_algs(out):
                            gamma=15.0, isotropic=True, niter=50, warm=True)
         d[f"{tag}_ulpda_mc"] = A.UnadjustedLangevinPrimalDual(mcu, O.L21(ndim=2, sigma=tau_reg), Gop, tau=tau0, mu=mu0,
                                                               theta=1.0, x0=x0, gfirst=False, niter=6, seed=seed)
+        # MYULA with the ME-TV data term (prox_lmc_deconv.py:506-515 pattern: M3)
+        meu = A.L2_ncvx_tv(dims=(ny, nx), Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg,
+                           gamma=15.0, isotropic=True, niter=50, warm=True)
+        d[f"{tag}_myula_me_tv"] = A.MoreauYosidaUnadjustedLangevin(
+            meu, O.TV((ny, nx), sigma=tau_reg, niter=10), tau=tau_myula, gamma=gamma_myula, x0=x0, niter=4, seed=seed)
         # MYULA with the non-log-concave data term (prox_lmc_deconv.py:492-501 pattern)
         d[f"{tag}_myula_mc_tv"] = A.MoreauYosidaUnadjustedLangevin(
             mc, O.TV((ny, nx), sigma=tau_reg, niter=10), tau=tau_myula, gamma=gamma_myula, x0=x0, niter=6, seed=seed)

@@ -83,9 +83,47 @@ def test_unbuilt_branches_raise(la):
     shape = (8, 8)
     H = la.Convolve2D(shape, np.ones((5, 5)) / 25)
     with pytest.raises(NotImplementedError):
-        la.L2_ncvx_tv(dims=shape, Op=H, b=np.zeros(64), isotropic=True)                       # ME-TV
-    with pytest.raises(NotImplementedError):
         la.L2_ncvx_tv(dims=shape, Op=H, Op2=la.Gradient(shape), b=np.zeros(64), isotropic=False)
+    me = la.L2_ncvx_tv(dims=shape, Op=H, b=np.zeros(64), isotropic=True, niter=5)
+    with pytest.raises(NotImplementedError):
+        me.prox(np.zeros(64), 0.5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_me_tv_value_grad_and_myula_match_reference_class(la, golden, tag):
+    """ME-TV branch (Op2 = None; TV prox with niter_l2 = 50 iterations inside the gradient, algs.py:169,282) against the
+    reference's own class; the 50 dual iterations are chained through HBM-resident state in chunks of 8."""
+    g = golden("algs.npz")
+    sigma, tau_reg, tau_myula, gamma_myula, tau0, mu0 = [float(v) for v in g["params"]]
+    ny, nx, k, seed = [int(v) for v in g[f"{tag}_meta"]]
+    h, y = g[f"{tag}_h"], g[f"{tag}_y"]
+    H = la.Convolve2D((ny, nx), h, offset=(k // 2, k // 2))
+    xt = g[f"{tag}_ncvx_x"]
+    me = la.L2_ncvx_tv(dims=(ny, nx), Op=H, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=15.0, isotropic=True,
+                       niter=50, warm=True)
+    got, ref = me.grad(xt.copy()), g[f"{tag}_ncvx_me_grad"]
+    l2o = O.L2(Op=O.Convolve2D((ny, nx), h, offset=(k // 2, k // 2)), b=y.ravel(), sigma=1 / sigma ** 2)
+    scale = (1 / sigma ** 2) * (np.linalg.norm(l2o.Op.rmatvec(l2o.Op.matvec(xt))) + np.linalg.norm(l2o.Op.rmatvec(y.ravel())))
+    assert np.linalg.norm(got - ref) < 2e-7 * scale and rel(got, ref) < 1e-4, rel(got, ref)
+    val = float(g[f"{tag}_ncvx_me_val"])
+    assert abs(me(xt.copy()) - val) < 1e-5 * abs(val)
+    gx = g[f"{tag}_myula_me_tv"]
+    out = la.MoreauYosidaUnadjustedLangevin(me, la.TV((ny, nx), sigma=tau_reg, niter=10), np.zeros(ny * nx), tau=tau_myula,
+                                            gamma=gamma_myula, niter=gx.shape[0], seed=seed, rng="pcg64")
+    assert rel(out, gx) < 5e-5, rel(out, gx)
+
+
+def test_chunked_tv_prox_is_exact(la):
+    """TV prox with K > 12 runs as chained chunks of 8 iterations (dual state in HBM): identical to the oracle's K iterations."""
+    rng = np.random.default_rng(1)
+    shape = (70, 90)
+    x = rng.normal(100, 15, (2,) + shape)
+    for K in (13, 24, 50, 64):
+        tv = la.TV(shape, sigma=1.0, niter=K)
+        out = tv.prox(x, 2.5)
+        for c in range(2):
+            # fp32 rounding grows with the number of momentum iterations (not with the chunking): 2e-6 per iteration
+            assert rel(out[c], O.tv_prox_fgp(x[c], 2.5, K)) < 2e-6 * K, (K, rel(out[c], O.tv_prox_fgp(x[c], 2.5, K)))
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])

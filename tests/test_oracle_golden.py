@@ -122,6 +122,10 @@ def test_l2_ncvx_tv_matches_reference_class(golden, tag):
     out = O.myula(mc, O.TV((ny, nx), sigma=tau_reg, niter=10), np.zeros(ny * nx), tau_myula, gamma_myula,
                   niter=gx.shape[0], seed=seed)
     np.testing.assert_allclose(out, gx, rtol=1e-12, atol=1e-11)
+    gx = g[f"{tag}_myula_me_tv"]
+    out = O.myula(me, O.TV((ny, nx), sigma=tau_reg, niter=10), np.zeros(ny * nx), tau_myula, gamma_myula,
+                  niter=gx.shape[0], seed=seed)
+    np.testing.assert_allclose(out, gx, rtol=1e-12, atol=1e-11)
 
 
 def test_batched_step_equals_single_chain_loop(golden):
