@@ -435,6 +435,12 @@ int lmc_l2_prox(const lmc_problem* prob, const float* x_dev, float* out_dev, int
   // floats: use r and p (both overwritten later by the solver) as a zeroed [n_img][2][H][W] field.
   if (q.ncvx_kind == LMC_NCVX_MC_TV) {
     HIP_TRY(lmc::ulpda_ncvx_rhs(x_dev, tmp, rhs, n_img, q.H, q.W, tau * q.ncvx_lambda, q.ncvx_gamma, ts, st));
+  } else if (q.ncvx_kind == LMC_NCVX_ME_TV) {
+    HIP_TRY(g_scratch.need_extra(n));
+    if (needs_tv_state(q)) HIP_TRY(g_scratch.need_state(4 * n));
+    rc = me_tv_prox(q, x_dev, g_scratch.extra, n_img, g_scratch.state[0], g_scratch.state[1], st);
+    if (rc) return rc;
+    HIP_TRY(lmc::ulpda_me_rhs(x_dev, g_scratch.extra, tmp, rhs, n_img, q.H, q.W, tau * q.ncvx_lambda / q.ncvx_gamma, ts, st));
   } else {
     HIP_TRY(hipMemsetAsync(r, 0, sizeof(float) * 2 * n, st));
     HIP_TRY(lmc::ulpda_rhs(x_dev, r, nullptr, tmp, rhs, n_img, q.H, q.W, 0.f, ts, st));
@@ -638,6 +644,11 @@ static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, h
     if (s->prob.ncvx_kind == LMC_NCVX_MC_TV) {   // L2_ncvx_tv.prox pre-step (algs.py:213-217), then + tau sigma H^T b (:225)
       HIP_TRY(lmc::ulpda_rhs(x, s->ydual, s->z, nullptr, s->ctmp, C, H, W, s->tau, ts, st));
       HIP_TRY(lmc::ulpda_ncvx_rhs(s->ctmp, s->htb, s->rhs, C, H, W, s->tau * s->prob.ncvx_lambda, s->prob.ncvx_gamma, ts, st));
+    } else if (s->prob.ncvx_kind == LMC_NCVX_ME_TV) {   // x += tau*lamda/gamma (x - prox_{gamma TV}(x))  (algs.py:221-223)
+      HIP_TRY(lmc::ulpda_rhs(x, s->ydual, s->z, nullptr, s->ctmp, C, H, W, s->tau, ts, st));
+      int rc = me_tv_prox(s->prob, s->ctmp, s->extra, C, s->tvstate[0], s->tvstate[1], st);
+      if (rc) return rc;
+      HIP_TRY(lmc::ulpda_me_rhs(s->ctmp, s->extra, s->htb, s->rhs, C, H, W, s->tau * s->prob.ncvx_lambda / s->prob.ncvx_gamma, ts, st));
     } else
     HIP_TRY(lmc::ulpda_rhs(x, s->ydual, s->z, s->prob.data_kind == LMC_DATA_BLUR ? s->htb : nullptr, s->rhs, C, H, W, s->tau, ts, st));
     const float* u = s->rhs;
@@ -683,8 +694,6 @@ int lmc_ulpda_create(const lmc_ulpda_config* cfg, lmc_sampler** out) {
     return fail(LMC_E_UNSUPPORTED, "ULPDA needs g o A with g = L21 (LMC_PRIOR_TV_ISO) or L1 (LMC_PRIOR_TV_ANISO)");
   if (!(cfg->problem.prior_sigma > 0.f)) return fail(LMC_E_INVALID, "prior_sigma (dual ball radius) must be > 0");
   if (cfg->problem.data_kind == LMC_DATA_BLUR && cfg->cg_niter < 1) return fail(LMC_E_INVALID, "cg_niter must be >= 1");
-  if (cfg->problem.ncvx_kind == LMC_NCVX_ME_TV)
-    return fail(LMC_E_UNSUPPORTED, "ULPDA with the ME-TV data term (L2_ncvx_tv.prox, algs.py:221-223) is not built");
   if (cfg->problem.ncvx_kind != LMC_NCVX_NONE && cfg->problem.data_kind != LMC_DATA_BLUR)
     return fail(LMC_E_UNSUPPORTED, "the non-convex term is built for the blur data term only (prox_lmc_deconv.py:106)");
   lmc_sampler* s = new (std::nothrow) lmc_sampler();
@@ -715,6 +724,10 @@ int lmc_ulpda_create(const lmc_ulpda_config* cfg, lmc_sampler** out) {
     if (e == hipSuccess) e = hipMalloc(&s->scal, sizeof(double) * 3 * s->C);
     if (e == hipSuccess) e = lmc::launch_blur(s->prob.y, s->htb, 1, s->prob.H, s->prob.W, s->prob.taps, 1, nullptr);   // H^T b
     if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  if (s->prob.ncvx_kind == LMC_NCVX_ME_TV) {
+    alloc(&s->extra, n);
+    if (needs_tv_state(s->prob)) { alloc(&s->tvstate[0], 4 * n); alloc(&s->tvstate[1], 4 * n); }
   }
   if (e == hipSuccess && s->moments) {
     const size_t mb = sizeof(double) * img;

@@ -53,6 +53,8 @@ namespace lmc {
 hipError_t ulpda_dual_update(const float* xhat, float* y, int64_t C, int H, int W, float mu, float radius, int iso, hipStream_t st);
 hipError_t ulpda_rhs(const float* x, const float* y, const float* z, const float* htb, float* rhs, int64_t C, int H, int W,
                      float tau, float ts, hipStream_t st);
+hipError_t ulpda_me_rhs(const float* v, const float* extra, const float* htb, float* rhs, int64_t C, int H, int W, float coef,
+                        float ts, hipStream_t st);
 hipError_t ulpda_ncvx_rhs(const float* v, const float* htb, float* rhs, int64_t C, int H, int W, float coef, float gamma, float ts,
                           hipStream_t st);
 hipError_t ulpda_pointwise_prox(const float* v, float* u, const float* b, const float* m, int64_t C, int H, int W, float ts,

@@ -85,6 +85,26 @@ __global__ __launch_bounds__(256) void ulpda_ncvx_rhs_kernel(const float* __rest
   }
 }
 
+// rhs = v + coef * (v - extra) + ts * Htb : ME-TV pre-step of L2_ncvx_tv.prox (algs.py:221-223), extra = prox_{gamma TV}(v)
+__global__ __launch_bounds__(256) void ulpda_me_rhs_kernel(const float* __restrict__ v, const float* __restrict__ extra,
+                                                           const float* __restrict__ htb, float* __restrict__ rhs, size_t img,
+                                                           int64_t C, float coef, float ts) {
+  const size_t total = img * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float x = v[i];
+    float out = fmaf(coef, x - extra[i], x);
+    if (htb) out = fmaf(ts, htb[i % img], out);
+    rhs[i] = out;
+  }
+}
+
+hipError_t ulpda_me_rhs(const float* v, const float* extra, const float* htb, float* rhs, int64_t C, int H, int W, float coef,
+                        float ts, hipStream_t st) {
+  hipLaunchKernelGGL(ulpda_me_rhs_kernel, dim3(grid1d((size_t)H * W * C, 256)), dim3(256), 0, st, v, extra, htb, rhs,
+                     (size_t)H * W, C, coef, ts);
+  return hipGetLastError();
+}
+
 hipError_t ulpda_ncvx_rhs(const float* v, const float* htb, float* rhs, int64_t C, int H, int W, float coef, float gamma, float ts,
                           hipStream_t st) {
   hipLaunchKernelGGL(ulpda_ncvx_rhs_kernel, dim3(grid1d((size_t)H * W * C, 256)), dim3(256), 0, st, v, htb, rhs, H, W, C, coef,

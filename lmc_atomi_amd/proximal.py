@@ -312,7 +312,7 @@ class L2_ncvx_tv(ProxOperator):
       ``prox`` (:201-267; also inside ULPDA, prox_lmc_deconv.py:478-487);
     * ME-TV (``Op2 = None``): value and gradient ``sigma Op^T(Op x - b) - lamda (x - prox_{gamma TV}(x))/gamma`` (:282), the inner
       TV prox with ``niter`` (= niter_l2 = 50) dual iterations chained exactly through HBM-resident dual state in chunks of 8.
-    Not built: anisotropic variants, ``prox`` of the ME-TV term -- they raise.
+    ``prox`` (:201-267) is built for both (ME-TV pre-step :221-223).  Not built: anisotropic variants -- they raise.
     """
 
     def __init__(self, dims, Op=None, Op2=None, b=None, q=None, sigma=1., alpha=1., lamda=1., gamma=.5, qgrad=True,
@@ -357,8 +357,6 @@ class L2_ncvx_tv(ProxOperator):
         """``L2_ncvx_tv.prox`` (algs.py:201-267), MC-TV branch: ``v <- x + tau*lamda*Op2^T(Op2 x / max(|Op2 x|, gamma))`` then
         ``(I + tau sigma Op^T Op)^{-1}(v + tau sigma Op^T b)`` by ``niter`` warm-started CG iterations (lmc_l2_prox).  Unlike
         the reference (which adds the first term into its argument in place, :217) the input is left untouched."""
-        if self.Op2 is None:
-            raise NotImplementedError("L2_ncvx_tv.prox for ME-TV (algs.py:221-223) is not built")
         prob = self._problem()
         n = self.dims[0] * self.dims[1]
         xt = _dev.to_dev(x)

@@ -553,9 +553,7 @@ class L2NcvxTV(_Prox):
         :func:`cg_solve` (SPD system, condition number <= 1 + tau*sigma: both are converged to round-off after the
         reference's 50 iterations -- checked against the reference's own output in tests/test_oracle_golden.py)."""
         x = np.array(x, dtype=np.float64, copy=True)
-        if self.Op2 is None:
-            raise NotImplementedError("ME-TV prox branch not restated")
-        x = x + tau * self.lamda * self.grad_moreau(x)                       # algs.py:213-217
+        x = x + tau * self.lamda * self.grad_moreau(x)                       # algs.py:213-217 (MC-TV) / :221-223 (ME-TV)
         y = x + tau * self.sigma * self.Op.rmatvec(self.b)                   # algs.py:225 (OpTb = sigma Op^T b, :159)
         ts = float(tau * self.sigma)
 

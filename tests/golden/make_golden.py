@@ -226,6 +226,14 @@ def gen_algs(out):
                            gamma=15.0, isotropic=True, niter=50, warm=True)
         d[f"{tag}_ulpda_mc"] = A.UnadjustedLangevinPrimalDual(mcu, O.L21(ndim=2, sigma=tau_reg), Gop, tau=tau0, mu=mu0,
                                                               theta=1.0, x0=x0, gfirst=False, niter=6, seed=seed)
+        # ME-TV: prox (algs.py:221-223 + LSQR) and ULPDA driven by it (prox_lmc_deconv.py:506-515 pattern, ULPDA branch)
+        mep = A.L2_ncvx_tv(dims=(ny, nx), Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg,
+                           gamma=15.0, isotropic=True, niter=50, warm=True)
+        d[f"{tag}_ncvx_me_prox_out"] = mep.prox(vp.copy(), tau0)
+        meq = A.L2_ncvx_tv(dims=(ny, nx), Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg,
+                           gamma=15.0, isotropic=True, niter=50, warm=True)
+        d[f"{tag}_ulpda_me"] = A.UnadjustedLangevinPrimalDual(meq, O.L21(ndim=2, sigma=tau_reg), Gop, tau=tau0, mu=mu0,
+                                                              theta=1.0, x0=x0, gfirst=False, niter=4, seed=seed)
         # MYULA with the ME-TV data term (prox_lmc_deconv.py:506-515 pattern: M3)
         meu = A.L2_ncvx_tv(dims=(ny, nx), Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg,
                            gamma=15.0, isotropic=True, niter=50, warm=True)

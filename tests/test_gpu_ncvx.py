@@ -84,9 +84,6 @@ def test_unbuilt_branches_raise(la):
     H = la.Convolve2D(shape, np.ones((5, 5)) / 25)
     with pytest.raises(NotImplementedError):
         la.L2_ncvx_tv(dims=shape, Op=H, Op2=la.Gradient(shape), b=np.zeros(64), isotropic=False)
-    me = la.L2_ncvx_tv(dims=shape, Op=H, b=np.zeros(64), isotropic=True, niter=5)
-    with pytest.raises(NotImplementedError):
-        me.prox(np.zeros(64), 0.5)
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
@@ -146,5 +143,13 @@ def test_ncvx_prox_and_ulpda_match_reference(la, golden, tag):
     assert rel(mc.prox(vp + 1.0, tau0), g[f"{tag}_ncvx_prox_out2"]) < 1e-4
     gx = g[f"{tag}_ulpda_mc"]
     xs = la.UnadjustedLangevinPrimalDual(mk(), la.L21(ndim=2, sigma=tau_reg), G, tau=tau0, mu=mu0, theta=1.0,
+                                         x0=np.zeros(ny * nx), gfirst=False, niter=gx.shape[0], seed=seed, rng="pcg64")
+    assert rel(xs, gx) < 2e-4, rel(xs, gx)
+    # ME-TV branch (algs.py:221-223)
+    mke = lambda: la.L2_ncvx_tv(dims=(ny, nx), Op=H, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=15.0,
+                                isotropic=True, niter=50, warm=True)
+    assert rel(mke().prox(vp, tau0), g[f"{tag}_ncvx_me_prox_out"]) < 1e-4
+    gx = g[f"{tag}_ulpda_me"]
+    xs = la.UnadjustedLangevinPrimalDual(mke(), la.L21(ndim=2, sigma=tau_reg), G, tau=tau0, mu=mu0, theta=1.0,
                                          x0=np.zeros(ny * nx), gfirst=False, niter=gx.shape[0], seed=seed, rng="pcg64")
     assert rel(xs, gx) < 2e-4, rel(xs, gx)

@@ -164,3 +164,11 @@ def test_l2_ncvx_tv_prox_and_ulpda_match_reference_lsqr_path(golden, tag):
     xs = O.ulpda(mcu, O.L21(ndim=2, sigma=tau_reg), Gop, np.zeros(ny * nx), tau0, mu0, theta=1.0, niter=gx.shape[0],
                  seed=seed, gfirst=False)
     assert rel(xs, gx) < 5e-5, rel(xs, gx)
+    # ME-TV branch of the same prox and ULPDA
+    me = O.L2NcvxTV((ny, nx), Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=15.0, niter=50)
+    assert rel(me.prox(vp.copy(), tau0), g[f"{tag}_ncvx_me_prox_out"]) < 5e-5
+    meu = O.L2NcvxTV((ny, nx), Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=15.0, niter=50)
+    gx = g[f"{tag}_ulpda_me"]
+    xs = O.ulpda(meu, O.L21(ndim=2, sigma=tau_reg), Gop, np.zeros(ny * nx), tau0, mu0, theta=1.0, niter=gx.shape[0],
+                 seed=seed, gfirst=False)
+    assert rel(xs, gx) < 5e-5, rel(xs, gx)
