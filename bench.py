@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--tv-iters", type=int, default=10)
     ap.add_argument("--prior", default="tv", choices=["tv", "l2", "l1"])
     ap.add_argument("--thin", type=int, default=1, help="accumulate posterior moments every thin-th iteration")
+    ap.add_argument("--alg", default="myula", choices=["myula", "ulpda"], help="sampler: MYULA (headline) or ULPDA (algs.py:295-474)")
+    ap.add_argument("--cg-iters", type=int, default=50, help="ULPDA: inner CG iterations of the implicit data step")
     ap.add_argument("--no-moments", action="store_true")
     ap.add_argument("--data", default="blur", choices=["blur", "identity"], help="data term (experiments)")
     ap.add_argument("--noise", default="philox", choices=["philox", "none"], help="noise source (experiments)")
@@ -116,8 +118,14 @@ def main():
         pf = la.L2(b=y, sigma=1 / sigma ** 2, dims=(H, W))
     pg = {"tv": la.TV((H, W), sigma=tau_reg, niter=args.tv_iters), "l2": la.L2(sigma=0.05),
           "l1": la.L1(sigma=tau_reg)}[args.prior]
-    smp = la.MYULASampler(pf, pg, (H, W), n_chains=C, tau=tau, gamma=gamma, seed=0, chain_offset=rank * C,
-                          moments=not args.no_moments, burn_in=0, thin=args.thin, noise=args.noise)
+    if args.alg == "ulpda":      # prox_lmc_deconv.py:88-90,455-457: tau0 = 0.95 sigma^2, mu0 = 1, theta = 1, gfirst = False
+        pf.niter = args.cg_iters
+        smp = la.ULPDASampler(pf, la.L21(ndim=2, sigma=tau_reg), la.Gradient((H, W)), (H, W), n_chains=C, tau=0.95 * sigma ** 2,
+                              mu=1.0, theta=1.0, gfirst=False, seed=0, chain_offset=rank * C, moments=not args.no_moments,
+                              burn_in=0, thin=args.thin, noise=args.noise)
+    else:
+        smp = la.MYULASampler(pf, pg, (H, W), n_chains=C, tau=tau, gamma=gamma, seed=0, chain_offset=rank * C,
+                              moments=not args.no_moments, burn_in=0, thin=args.thin, noise=args.noise)
     smp.set_state(np.zeros((H, W), dtype=np.float32))        # x0 = 0 (prox_lmc_deconv.py:135)
 
     def sync_all():
@@ -129,7 +137,8 @@ def main():
     smp.step(args.warmup)
     if not args.no_moments:
         smp.reset_moments()
-    smp.enable_timing(True)
+    if args.alg == "myula":
+        smp.enable_timing(True)
     sync_all()
     t0 = time.perf_counter()
     smp.step(args.steps)
@@ -143,7 +152,10 @@ def main():
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
-    kern_ms, launches = smp.last_step_timing()
+    if args.alg == "myula":
+        kern_ms, launches = smp.last_step_timing()
+    else:                        # ULPDA is a sequence of launches per iteration: quote the whole iteration
+        kern_ms, launches = elapsed * 1e3, args.steps
 
     if rank == 0:
         # HBM bytes per launch from the committed rocprofv3 PMC passes (they cannot be collected inside this process);
@@ -178,7 +190,7 @@ def main():
                             f"{C} chains/GPU x {world} GPU, Philox noise, x0=0, "
                             + ("no moments" if args.no_moments else f"posterior moments every {args.thin} it"),
                 "image": [H, W], "chains_per_gpu": C, "chains_total": C * world, "tv_iters": args.tv_iters,
-                "sampler": "MYULA (algs.py:477-587)", "parallelism": f"chains sharded x{world}",
+                "sampler": "MYULA (algs.py:477-587)" if args.alg == "myula" else f"ULPDA (algs.py:295-474), {args.cg_iters} CG iterations per implicit step", "parallelism": f"chains sharded x{world}",
                 "iterations_per_s": args.steps / elapsed,
             },
             "roofline": {

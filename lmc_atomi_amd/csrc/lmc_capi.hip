@@ -232,6 +232,36 @@ hipError_t launch_step(const lmc::StepArgs& A, hipStream_t st, const char** name
   return lmc::launch_step_tile(A, st);
 }
 
+// Conjugate gradients on (I + ts H^T H) u = rhs for every chain, `niter` iterations from the current u.
+// The operator q = p + ts H^T H p is ONE launch of the fused step kernel (out = 1*p - t*grad f(p) with y = 0 and
+// t = -ts/sigma_f), i.e. the same blur pipeline as the sampler; zero_y is an all-zero [H][W] image.
+int cg_solve_fused(const Problem& q, float ts, float* u, const float* rhs, float* r, float* p, float* qq, double* scal,
+                   int64_t C, int niter, const float* zero_y, hipStream_t st) {
+  const size_t img = (size_t)q.H * q.W;
+  double *rs = scal, *pq = scal + C, *rs_new = scal + 2 * C;
+  lmc::StepArgs A;
+  std::memset(&A, 0, sizeof A);
+  A.H = q.H; A.W = q.W; A.C = (int)C;
+  A.data_kind = LMC_DATA_BLUR; A.sigma_f = q.sigma_f; A.blur = q.taps;
+  A.y = zero_y; A.mask = zero_y; A.noise = zero_y;
+  A.prior_kind = LMC_PRIOR_NONE;
+  A.a = 1.f; A.t = -ts / q.sigma_f; A.b = 0.f; A.s = 0.f;
+  A.noise_mode = LMC_NOISE_NONE;
+  auto apply = [&](const float* in, float* out) -> hipError_t { A.x_in = in; A.x_out = out; return launch_step(A, st, nullptr); };
+  HIP_TRY(hipMemsetAsync(scal, 0, sizeof(double) * 3 * C, st));
+  HIP_TRY(apply(u, qq));
+  HIP_TRY(lmc::cg_init(rhs, qq, r, p, C, img, rs, st));
+  for (int it = 0; it < niter; ++it) {
+    HIP_TRY(hipMemsetAsync(pq, 0, sizeof(double) * 2 * C, st));     // pq and rs_new are adjacent
+    HIP_TRY(apply(p, qq));
+    HIP_TRY(lmc::cg_dot(p, qq, C, img, pq, st));
+    HIP_TRY(lmc::cg_update(u, r, p, qq, C, img, rs, pq, rs_new, st));
+    HIP_TRY(lmc::cg_dir(p, r, C, img, rs, rs_new, st));
+    HIP_TRY(hipMemcpyAsync(rs, rs_new, sizeof(double) * C, hipMemcpyDeviceToDevice, st));
+  }
+  return LMC_OK;
+}
+
 bool needs_tv_state(const Problem& q) {
   return (q.prior_kind == LMC_PRIOR_TV_ISO && q.tv_niter > 12) || (q.ncvx_kind == LMC_NCVX_ME_TV && q.ncvx_niter > 12);
 }
@@ -267,7 +297,7 @@ struct lmc_sampler {
   const float* z = nullptr;
   float* xhat = nullptr; float* ydual = nullptr; float* uw = nullptr; float* rhs = nullptr;
   float* cr = nullptr; float* cp = nullptr; float* cq = nullptr; float* ctmp = nullptr; float* xi = nullptr;
-  float* htb = nullptr; double* scal = nullptr;
+  float* htb = nullptr; double* scal = nullptr; float* zero_y = nullptr;
   float* tvstate[2] = {nullptr, nullptr};   // dual-state ping-pong for chunked TV proxes (K > 12, ME-TV)
   float* extra = nullptr;                   // ME-TV inner prox
   Problem prob;
@@ -446,7 +476,9 @@ int lmc_l2_prox(const lmc_problem* prob, const float* x_dev, float* out_dev, int
     HIP_TRY(lmc::ulpda_rhs(x_dev, r, nullptr, tmp, rhs, n_img, q.H, q.W, 0.f, ts, st));
   }
   if (!warm) HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(float) * n, st));
-  HIP_TRY(lmc::ulpda_cg_solve(out_dev, rhs, r, p, qq, tmp, scal, n_img, q.H, q.W, q.taps, ts, niter, st));
+  HIP_TRY(hipMemsetAsync(tmp, 0, sizeof(float) * (size_t)q.H * q.W, st));   // tmp (H^T y) is consumed: reuse its first image as the zero observation
+  rc = cg_solve_fused(q, ts, out_dev, rhs, r, p, qq, scal, n_img, niter, tmp, st);
+  if (rc) return rc;
   return LMC_OK;
 }
 
@@ -530,7 +562,7 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
 
 void lmc_sampler_destroy(lmc_sampler* s) {
   if (!s) return;
-  for (float* b : {s->xhat, s->ydual, s->uw, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra})
+  for (float* b : {s->zero_y, s->xhat, s->ydual, s->uw, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra})
     if (b) (void)hipFree(b);
   if (s->scal) (void)hipFree(s->scal);
   if (s->x[0]) (void)hipFree(s->x[0]);
@@ -654,7 +686,7 @@ static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, h
     const float* u = s->rhs;
     if (s->prob.data_kind == LMC_DATA_BLUR) {
       if (!s->warm) HIP_TRY(hipMemsetAsync(s->uw, 0, sizeof(float) * per_iter, st));
-      HIP_TRY(lmc::ulpda_cg_solve(s->uw, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->scal, C, H, W, s->prob.taps, ts, s->cg_niter, st));
+      { int rc = cg_solve_fused(s->prob, ts, s->uw, s->rhs, s->cr, s->cp, s->cq, s->scal, C, s->cg_niter, s->zero_y, st); if (rc) return rc; }
       u = s->uw;
     } else if (s->prob.data_kind != LMC_DATA_NONE) {
       HIP_TRY(lmc::ulpda_pointwise_prox(s->rhs, s->uw, s->prob.y, s->prob.mask, C, H, W, ts, s->prob.data_kind, st));
@@ -720,7 +752,7 @@ int lmc_ulpda_create(const lmc_ulpda_config* cfg, lmc_sampler** out) {
   alloc(&s->x[0], n); alloc(&s->xhat, n); alloc(&s->ydual, 2 * n); alloc(&s->uw, n); alloc(&s->rhs, n);
   if (s->noise_mode == LMC_NOISE_PHILOX) alloc(&s->xi, n);
   if (s->prob.data_kind == LMC_DATA_BLUR) {
-    alloc(&s->cr, n); alloc(&s->cp, n); alloc(&s->cq, n); alloc(&s->ctmp, n); alloc(&s->htb, img);
+    alloc(&s->cr, n); alloc(&s->cp, n); alloc(&s->cq, n); alloc(&s->ctmp, n); alloc(&s->htb, img); alloc(&s->zero_y, img);
     if (e == hipSuccess) e = hipMalloc(&s->scal, sizeof(double) * 3 * s->C);
     if (e == hipSuccess) e = lmc::launch_blur(s->prob.y, s->htb, 1, s->prob.H, s->prob.W, s->prob.taps, 1, nullptr);   // H^T b
     if (e == hipSuccess) e = hipDeviceSynchronize();

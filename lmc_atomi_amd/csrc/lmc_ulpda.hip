@@ -199,6 +199,42 @@ __global__ __launch_bounds__(256) void ulpda_finish_kernel(float* __restrict__ x
   }
 }
 
+// pq[c] = dot(p_c, q_c)
+__global__ __launch_bounds__(256) void cg_dot_kernel(const float* __restrict__ p, const float* __restrict__ q, size_t img,
+                                                     double* __restrict__ pq) {
+  __shared__ double scratch[4];
+  const size_t c = blockIdx.y;
+  double acc = 0.0;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.x * blockDim.x)
+    acc += (double)p[c * img + k] * (double)q[c * img + k];
+  const double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) unsafeAtomicAdd(&pq[c], t);
+}
+
+static inline dim3 cg_grid(size_t img, int64_t C) {
+  int gx = (int)((img + 255) / 256);
+  if (gx > 128) gx = 128;
+  return dim3(gx, (unsigned)C);
+}
+
+hipError_t cg_dot(const float* p, const float* q, int64_t C, size_t img, double* pq, hipStream_t st) {
+  hipLaunchKernelGGL(cg_dot_kernel, cg_grid(img, C), dim3(256), 0, st, p, q, img, pq);
+  return hipGetLastError();
+}
+hipError_t cg_init(const float* rhs, const float* q, float* r, float* p, int64_t C, size_t img, double* rs, hipStream_t st) {
+  hipLaunchKernelGGL(cg_init_kernel, cg_grid(img, C), dim3(256), 0, st, rhs, q, r, p, img, rs);
+  return hipGetLastError();
+}
+hipError_t cg_update(float* u, float* r, const float* p, const float* q, int64_t C, size_t img, const double* rs, const double* pq,
+                     double* rs_new, hipStream_t st) {
+  hipLaunchKernelGGL(cg_update_kernel, cg_grid(img, C), dim3(256), 0, st, u, r, p, q, img, rs, pq, rs_new);
+  return hipGetLastError();
+}
+hipError_t cg_dir(float* p, const float* r, int64_t C, size_t img, const double* rs, const double* rs_new, hipStream_t st) {
+  hipLaunchKernelGGL(cg_dir_kernel, cg_grid(img, C), dim3(256), 0, st, p, r, img, rs, rs_new);
+  return hipGetLastError();
+}
+
 // ---- host-side sequences --------------------------------------------------------------------------------
 
 hipError_t ulpda_dual_update(const float* xhat, float* y, int64_t C, int H, int W, float mu, float radius, int iso,
