@@ -73,12 +73,12 @@ def main():
     ap.add_argument("--width", type=int, default=0, help="image width if not square (experiments)")
     ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
     ap.add_argument("--tv-iters", type=int, default=10)
-    ap.add_argument("--prior", default="tv", choices=["tv", "l2", "l1"])
+    ap.add_argument("--prior", default="tv", choices=["tv", "l2", "l1", "haar"])
     ap.add_argument("--thin", type=int, default=1, help="accumulate posterior moments every thin-th iteration")
     ap.add_argument("--alg", default="myula", choices=["myula", "ulpda"], help="sampler: MYULA (headline) or ULPDA (algs.py:295-474)")
     ap.add_argument("--cg-iters", type=int, default=50, help="ULPDA: inner CG iterations of the implicit data step")
     ap.add_argument("--no-moments", action="store_true")
-    ap.add_argument("--data", default="blur", choices=["blur", "identity"], help="data term (experiments)")
+    ap.add_argument("--data", default="blur", choices=["blur", "identity", "mask"], help="data term (experiments)")
     ap.add_argument("--noise", default="philox", choices=["philox", "none"], help="noise source (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chains", type=int, default=4)
@@ -114,10 +114,13 @@ def main():
     u, h, y = synth_problem(H, W, sigma)
     if args.data == "blur":
         pf = la.L2(Op=la.Convolve2D((H, W), h, offset=(2, 2)), b=y, sigma=1 / sigma ** 2)
+    elif args.data == "mask":                        # inpainting: 60 % of the pixels observed
+        m = (np.random.default_rng(7).uniform(size=(H, W)) < 0.6).astype(np.float32)
+        pf = la.L2(Op=la.Diagonal(m, dims=(H, W)), b=m * u, sigma=1 / sigma ** 2, dims=(H, W))
     else:
         pf = la.L2(b=y, sigma=1 / sigma ** 2, dims=(H, W))
-    pg = {"tv": la.TV((H, W), sigma=tau_reg, niter=args.tv_iters), "l2": la.L2(sigma=0.05),
-          "l1": la.L1(sigma=tau_reg)}[args.prior]
+    pg = {"tv": lambda: la.TV((H, W), sigma=tau_reg, niter=args.tv_iters), "l2": lambda: la.L2(sigma=0.05),
+          "l1": lambda: la.L1(sigma=tau_reg), "haar": lambda: la.WaveletL1((H, W), sigma=tau_reg)}[args.prior]()
     if args.alg == "ulpda":      # prox_lmc_deconv.py:88-90,455-457: tau0 = 0.95 sigma^2, mu0 = 1, theta = 1, gfirst = False
         pf.niter = args.cg_iters
         smp = la.ULPDASampler(pf, la.L21(ndim=2, sigma=tau_reg), la.Gradient((H, W)), (H, W), n_chains=C, tau=0.95 * sigma ** 2,
@@ -186,7 +189,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{H}x{W} MYULA deblur (5x5 uniform box blur, sigma={sigma}) + {prior_desc}, "
+                "workload": f"{H}x{W} MYULA " + {"blur": f"deblur (5x5 uniform box blur, sigma={sigma})", "mask": "inpainting (60 % mask)",
+                                                   "identity": "denoise"}[args.data] + f" + {prior_desc}, "
                             f"{C} chains/GPU x {world} GPU, Philox noise, x0=0, "
                             + ("no moments" if args.no_moments else f"posterior moments every {args.thin} it"),
                 "image": [H, W], "chains_per_gpu": C, "chains_total": C * world, "tv_iters": args.tv_iters,

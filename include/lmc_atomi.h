@@ -54,7 +54,9 @@ typedef enum lmc_prior_kind {
   LMC_PRIOR_L1 = 2,     /* g = sigma ||x||_1        : soft threshold t*sigma  (prox.py:18) */
   LMC_PRIOR_TV_ISO = 3, /* g = sigma TV_iso(x)      : tv_niter FGP dual iterations (pyproximal.TV, prox_lmc_deconv.py:122);
                          *  in ULPDA: g o A with g = sigma*L21 (prox_lmc_deconv.py:116), dual prox = l2-ball projection */
-  LMC_PRIOR_TV_ANISO = 4 /* ULPDA / energies only: g o A with g = sigma*L1 (prox_lmc_deconv.py:119), dual prox = clip */
+  LMC_PRIOR_TV_ANISO = 4, /* ULPDA / energies only: g o A with g = sigma*L1 (prox_lmc_deconv.py:119), dual prox = clip */
+  LMC_PRIOR_HAAR_L1 = 5  /* g = sigma * || detail coefficients of the 3-level orthonormal Haar transform of x ||_1 (BASELINE
+                          * config 5; no counterpart in the reference): prox = W^T soft(W x, t*sigma); H, W multiples of 8 */
 } lmc_prior_kind;
 
 typedef enum lmc_ncvx_kind {
@@ -136,6 +138,9 @@ int lmc_l2_prox(const lmc_problem* prob, const float* x_dev, float* out_dev, int
  * Replaces proxf(x), proxg(x) of the energy log (algs.py:461-466, 578-582). */
 int lmc_energies(const lmc_problem* prob, const float* x_dev, int64_t n_img,
                  double* f_out_dev, double* g_out_dev, void* stream);
+
+/* out = prox_{thr * ||W_detail . ||_1}(x): 3-level orthonormal Haar, soft threshold of the detail coefficients.  H, W % 8 == 0. */
+int lmc_haar_l1_prox(const float* x_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W, float thr, void* stream);
 
 /* Per-pixel projection of the stacked field y[2][H][W] onto the l2 ball (isotropic != 0) or the
  * box (isotropic == 0) of radius `radius`: L21.proxdual / L1.proxdual (algs.py:436,448). */
@@ -243,7 +248,8 @@ int lmc_sampler_set_steps(lmc_sampler* s, float tau, float mu);
 
 /* Step-kernel variant used by lmc_sampler_step / lmc_fused_eval: 0 = auto (default), 1 = LDS-tiled,
  * 2 = streaming register pipeline (one wave group), 3 = the same pipeline split over two wave groups,
- * 4 = HBM-bound tiled kernel for closed-form priors.  Returns the previous setting (>= 0) or a negative lmc_status.
+ * 4 = HBM-bound tiled kernel for closed-form priors, 5 = register-block kernel (stencil-free data term, prox local to
+ * 8 x 8 blocks: Haar-l1 / l2 / l1 / none; H, W multiples of 8).  Returns the previous setting (>= 0) or a negative lmc_status.
  * Both variants compute the same update; the switch exists for A/B tests and profiles. */
 int lmc_set_step_variant(int32_t variant);
 

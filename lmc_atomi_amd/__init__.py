@@ -5,7 +5,7 @@ is missing or no GPU is present."""
 from . import _capi
 from ._capi import LMCError
 from .operators import Convolve2D, Diagonal, Gradient, Identity, LinearOperator
-from .proximal import L1, L2, L21, TV, L2_ncvx_tv, ProxOperator, fgp_betas
+from .proximal import L1, L2, L21, TV, L2_ncvx_tv, WaveletL1, ProxOperator, fgp_betas
 from .algs import (MYULAResult, MYULASampler, MoreauYosidaUnadjustedLangevin, ULPDASampler,
                    UnadjustedLangevinPrimalDual, mean_var_from_moments,
                    set_step_variant)
@@ -18,7 +18,7 @@ __all__ = [
     "metrics", "MetricsCallback", "mean_squared_error", "peak_signal_noise_ratio", "signal_noise_ratio",
     "allreduce_moments", "chain_shard", "posterior_mean_var", "sharded_myula",
     "LMCError", "Convolve2D", "Diagonal", "Gradient", "Identity", "LinearOperator",
-    "L1", "L2", "L21", "TV", "L2_ncvx_tv", "ProxOperator", "fgp_betas",
+    "L1", "L2", "L21", "TV", "L2_ncvx_tv", "WaveletL1", "ProxOperator", "fgp_betas",
     "MYULASampler", "MYULAResult", "MoreauYosidaUnadjustedLangevin", "ULPDASampler", "UnadjustedLangevinPrimalDual", "mean_var_from_moments", "set_step_variant",
 ]
 __version__ = "0.1.0"

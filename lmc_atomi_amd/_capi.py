@@ -15,7 +15,7 @@ ABI_VERSION = 1
 
 # enums (include/lmc_atomi.h)
 DATA_NONE, DATA_IDENTITY, DATA_BLUR, DATA_MASK = 0, 1, 2, 3
-PRIOR_NONE, PRIOR_L2, PRIOR_L1, PRIOR_TV_ISO, PRIOR_TV_ANISO = 0, 1, 2, 3, 4
+PRIOR_NONE, PRIOR_L2, PRIOR_L1, PRIOR_TV_ISO, PRIOR_TV_ANISO, PRIOR_HAAR_L1 = 0, 1, 2, 3, 4, 5
 NOISE_PHILOX, NOISE_INJECTED, NOISE_NONE = 0, 1, 2
 NCVX_NONE, NCVX_MC_TV, NCVX_ME_TV = 0, 1, 2
 MAX_BLUR = 9
@@ -100,6 +100,7 @@ _SIGNATURES = {
     "lmc_l2_prox_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "lmc_l2_prox": (C.c_int, [C.POINTER(lmc_problem), _P, _P, C.c_int64, C.c_float, C.c_int32, C.c_int32, _P, _P]),
     "lmc_energies": (C.c_int, [C.POINTER(lmc_problem), _P, C.c_int64, _P, _P, _P]),
+    "lmc_haar_l1_prox": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, _P]),
     "lmc_dual_project": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
     "lmc_prox_elementwise": (C.c_int, [C.c_int32, _P, _P, C.c_int64, _F, C.c_int32, _P]),
     "lmc_myula_create": (C.c_int, [C.POINTER(lmc_myula_config), C.POINTER(_P)]),

@@ -76,8 +76,17 @@ struct Problem {
 struct Scratch {
   float* state[2] = {nullptr, nullptr};   // TV dual state ping-pong, [n][4][H][W] each
   float* extra = nullptr;                 // ME-TV inner prox, [n][H][W]
+  float* prox = nullptr;                  // Haar-l1 prox, [n][H][W]
   double* dbl = nullptr;                  // 2*n doubles
-  size_t n_state = 0, n_extra = 0, n_dbl = 0;
+  size_t n_state = 0, n_extra = 0, n_dbl = 0, n_prox = 0;
+  hipError_t need_prox(size_t n) {
+    if (n <= n_prox) return hipSuccess;
+    if (prox) (void)hipFree(prox);
+    prox = nullptr; n_prox = 0;
+    hipError_t e = hipMalloc(&prox, sizeof(float) * n);
+    if (e == hipSuccess) n_prox = n;
+    return e;
+  }
   hipError_t need_state(size_t n) {
     if (n <= n_state) return hipSuccess;
     for (float*& p : state) { if (p) (void)hipFree(p); p = nullptr; }
@@ -142,6 +151,9 @@ int load_problem(const lmc_problem* p, Problem& q) {
   q.prior_sigma = p->prior_sigma;
   switch (p->prior_kind) {
     case LMC_PRIOR_NONE: case LMC_PRIOR_L2: case LMC_PRIOR_L1: case LMC_PRIOR_TV_ANISO: break;
+    case LMC_PRIOR_HAAR_L1:
+      if ((p->H & 7) || (p->W & 7)) return fail(LMC_E_UNSUPPORTED, "the Haar-l1 prior needs H and W to be multiples of 8 (got %dx%d)", p->H, p->W);
+      break;
     case LMC_PRIOR_TV_ISO:
       if (p->tv_niter < 1 || p->tv_niter > lmc::kMaxTvIters)
         return fail(LMC_E_UNSUPPORTED, "tv_niter %d outside 1..%d", p->tv_niter, lmc::kMaxTvIters);
@@ -172,6 +184,7 @@ int make_step_args(const Problem& q, float a, float t, float b, float pt, float 
   A.y = q.y; A.mask = q.mask;
   A.blur = q.taps;
   A.prior_kind = (b == 0.f) ? LMC_PRIOR_NONE : q.prior_kind;
+  if (A.prior_kind == LMC_PRIOR_HAAR_L1) A.prior_p0 = pt * q.prior_sigma;  // soft threshold of the detail coefficients
   if (A.prior_kind == LMC_PRIOR_L2) A.prior_p0 = 1.f / (1.f + pt * q.prior_sigma);
   if (A.prior_kind == LMC_PRIOR_L1) A.prior_p0 = pt * q.prior_sigma;
   if (A.prior_kind == LMC_PRIOR_TV_ISO) {
@@ -199,13 +212,27 @@ void sanitize_pointers(lmc::StepArgs& A) {
   if (!A.noise) A.noise = A.x_in;
 }
 
-int g_variant = 0;  // 0 auto, 1 tile, 2 stream, 3 split, 4 point
+int g_variant = 0;  // 0 auto, 1 tile, 2 stream, 3 split, 4 point, 5 block
 
 // Picks the step-kernel variant.  auto: the split streaming pipeline (two wave groups, 4 waves/SIMD) when
 // it covers the configuration (W <= 512, separable blur <= 7x7, supported K), else the LDS-tiled kernel.
-hipError_t launch_step(const lmc::StepArgs& A, hipStream_t st, const char** name, float* state0 = nullptr,
-                       float* state1 = nullptr) {
+hipError_t launch_step(const lmc::StepArgs& A_in, hipStream_t st, const char** name, float* state0 = nullptr,
+                       float* state1 = nullptr, float* pxbuf = nullptr) {
   int v = g_variant;
+  // no stencil in the data term and a prox local to 8 x 8 blocks (Haar-l1, l2, l1, none): the register-block kernel
+  if ((v == 0 || v == 5) && lmc::block_supported(A_in)) {
+    if (name) *name = "myula_step_block_kernel";
+    return lmc::launch_step_block(A_in, st);
+  }
+  if (v == 5) return hipErrorInvalidConfiguration;
+  lmc::StepArgs A = A_in;
+  if (A.prior_kind == LMC_PRIOR_HAAR_L1) {   // other data terms: the block-wavelet prox first, consumed by the fused step kernel
+    if (!pxbuf) return hipErrorInvalidConfiguration;
+    hipError_t e = lmc::launch_haar_prox(A.x_in, pxbuf, A.C, A.H, A.W, A.prior_p0, st);
+    if (e != hipSuccess) return e;
+    A.prior_kind = LMC_PRIOR_NONE;
+    A.prox_ext = pxbuf;
+  }
   // auto: split pipeline when it covers the configuration (W <= 512); for wider images the tiled kernels:
   // "point" for closed-form priors with a separable blur, else the general LDS-tiled kernel
   if (v == 0) v = lmc::split_supported(A) ? 3 : (lmc::point_supported(A) ? 4 : (lmc::stream_supported(A) ? 2 : 1));
@@ -300,6 +327,7 @@ struct lmc_sampler {
   float* htb = nullptr; double* scal = nullptr; float* zero_y = nullptr;
   float* tvstate[2] = {nullptr, nullptr};   // dual-state ping-pong for chunked TV proxes (K > 12, ME-TV)
   float* extra = nullptr;                   // ME-TV inner prox
+  float* pxbuf = nullptr;                   // Haar-l1 prox of the current state
   Problem prob;
   int C = 0;
   int64_t chain_offset = 0;
@@ -388,7 +416,8 @@ int lmc_fused_eval(const lmc_problem* prob, const float* x_dev, float* out_dev, 
     A.extra = g_scratch.extra;
     A.extra_coef = -q.ncvx_lambda / q.ncvx_gamma;
   }
-  hipError_t e = launch_step(A, S(stream), nullptr, g_scratch.state[0], g_scratch.state[1]);
+  if (A.prior_kind == LMC_PRIOR_HAAR_L1) HIP_TRY(g_scratch.need_prox(npx));
+  hipError_t e = launch_step(A, S(stream), nullptr, g_scratch.state[0], g_scratch.state[1], g_scratch.prox);
   if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no step-kernel variant covers this configuration");
   HIP_TRY(e);
   return LMC_OK;
@@ -424,6 +453,7 @@ int lmc_energies(const lmc_problem* prob, const float* x_dev, int64_t n_img, dou
   if (rc) return rc;
   if (!x_dev || n_img < 1) return fail(LMC_E_INVALID, "bad arguments");
   HIP_TRY(lmc::launch_energies(x_dev, n_img, energy_args(q), f_out_dev, g_out_dev, S(stream)));
+  if (q.prior_kind == LMC_PRIOR_HAAR_L1 && g_out_dev) HIP_TRY(lmc::launch_haar_value(x_dev, n_img, q.H, q.W, q.prior_sigma, g_out_dev, S(stream)));
   if (q.ncvx_kind == LMC_NCVX_ME_TV && f_out_dev) {
     const size_t npx = (size_t)n_img * q.H * q.W;
     HIP_TRY(g_scratch.need_state(4 * npx));
@@ -479,6 +509,14 @@ int lmc_l2_prox(const lmc_problem* prob, const float* x_dev, float* out_dev, int
   HIP_TRY(hipMemsetAsync(tmp, 0, sizeof(float) * (size_t)q.H * q.W, st));   // tmp (H^T y) is consumed: reuse its first image as the zero observation
   rc = cg_solve_fused(q, ts, out_dev, rhs, r, p, qq, scal, n_img, niter, tmp, st);
   if (rc) return rc;
+  return LMC_OK;
+}
+
+int lmc_haar_l1_prox(const float* x_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W, float thr, void* stream) {
+  if (!x_dev || !out_dev || n_img < 1 || H < 8 || W < 8) return fail(LMC_E_INVALID, "bad arguments");
+  if ((H & 7) || (W & 7)) return fail(LMC_E_UNSUPPORTED, "H and W must be multiples of 8 (got %dx%d)", H, W);
+  if (!(thr >= 0.f)) return fail(LMC_E_INVALID, "threshold must be >= 0");
+  HIP_TRY(lmc::launch_haar_prox(x_dev, out_dev, n_img, H, W, thr, S(stream)));
   return LMC_OK;
 }
 
@@ -543,6 +581,7 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
     if (e == hipSuccess) e = hipMalloc(&s->tvstate[1], 4 * nbytes);
   }
   if (e == hipSuccess && s->prob.ncvx_kind == LMC_NCVX_ME_TV) e = hipMalloc(&s->extra, nbytes);
+  if (e == hipSuccess && s->prob.prior_kind == LMC_PRIOR_HAAR_L1) e = hipMalloc(&s->pxbuf, nbytes);
   if (e == hipSuccess && s->moments) {
     const size_t mb = sizeof(double) * (size_t)s->prob.H * s->prob.W;
     e = hipMalloc(&s->s1, mb);
@@ -562,7 +601,7 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
 
 void lmc_sampler_destroy(lmc_sampler* s) {
   if (!s) return;
-  for (float* b : {s->zero_y, s->xhat, s->ydual, s->uw, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra})
+  for (float* b : {s->zero_y, s->xhat, s->ydual, s->uw, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra, s->pxbuf})
     if (b) (void)hipFree(b);
   if (s->scal) (void)hipFree(s->scal);
   if (s->x[0]) (void)hipFree(s->x[0]);
@@ -633,7 +672,7 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     }
     if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * k], st));
     const char* kname = nullptr;
-    hipError_t e = launch_step(A, st, &kname, s->tvstate[0], s->tvstate[1]);
+    hipError_t e = launch_step(A, st, &kname, s->tvstate[0], s->tvstate[1], s->pxbuf);
     if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no step-kernel variant covers this configuration");
     HIP_TRY(e);
     if (kname) s->kernel_name = kname;
@@ -832,6 +871,8 @@ int lmc_sampler_reset_moments(lmc_sampler* s, void* stream) {
 int lmc_sampler_energies(lmc_sampler* s, double* f_out_dev, double* g_out_dev, void* stream) {
   if (!s) return fail(LMC_E_INVALID, "NULL sampler");
   HIP_TRY(lmc::launch_energies(s->x[s->cur], s->C, energy_args(s->prob), f_out_dev, g_out_dev, S(stream)));
+  if (s->prob.prior_kind == LMC_PRIOR_HAAR_L1 && g_out_dev)
+    HIP_TRY(lmc::launch_haar_value(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->prob.prior_sigma, g_out_dev, S(stream)));
   if (s->prob.ncvx_kind == LMC_NCVX_ME_TV && f_out_dev) {
     HIP_TRY(g_scratch.need_dbl(2 * (size_t)s->C));
     int rc = me_tv_energy(s->prob, s->x[s->cur], s->C, f_out_dev, s->extra, s->tvstate[0], s->tvstate[1], g_scratch.dbl, S(stream));
@@ -867,7 +908,8 @@ int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_lau
 const char* lmc_sampler_kernel_name(const lmc_sampler* s) { return s ? s->kernel_name.c_str() : ""; }
 
 int lmc_set_step_variant(int32_t variant) {
-  if (variant < 0 || variant > 4) return fail(LMC_E_INVALID, "variant must be 0 (auto), 1 (tile), 2 (stream), 3 (split) or 4 (point)");
+  if (variant < 0 || variant > 5)
+    return fail(LMC_E_INVALID, "variant must be 0 (auto), 1 (tile), 2 (stream), 3 (split), 4 (point) or 5 (block)");
   const int prev = g_variant;
   g_variant = variant;
   return prev;

@@ -53,6 +53,8 @@ struct StepArgs {
   // extra gradient term g += extra_coef * (x - extra[c][i][j])   (ME-TV: extra = prox_{gamma TV}(x), algs.py:282)
   const float* extra;
   float extra_coef;
+  // prox computed by a preceding launch (Haar-l1 wavelet prior): px = prox_ext[c][i][j]; the kernel's own prior is NONE
+  const float* prox_ext;
 };
 
 constexpr uint32_t kPhiloxStream = 0x4C4D4301u;  // counter word 3

@@ -28,6 +28,8 @@ hipError_t launch_gradient(const float* x, float* out, int64_t n_img, int H, int
 hipError_t launch_dual_project(const float* y, float* out, int64_t n_img, int H, int W, float radius, int iso,
                                hipStream_t st);
 hipError_t launch_eprox(int kind, const float* x, float* out, int64_t n, float p0, float p1, hipStream_t st);
+hipError_t launch_haar_prox(const float* x, float* out, int64_t n_img, int H, int W, float thr, hipStream_t st);
+hipError_t launch_haar_value(const float* x, int64_t n_img, int H, int W, float sigma, double* val, hipStream_t st);
 hipError_t launch_moments(const float* x, int C, int H, int W, double* s1, double* s2, hipStream_t st);
 hipError_t launch_energies(const float* x, int64_t n_img, const EnergyArgs& E, double* f_out, double* g_out,
                            hipStream_t st);
@@ -43,6 +45,9 @@ hipError_t launch_step_stream(StepArgs a, hipStream_t st);
 // HBM-bound tiled kernel for closed-form priors (lmc_step_point.hip)
 bool point_supported(const StepArgs& a);
 hipError_t launch_step_point(StepArgs a, hipStream_t st);
+// register-block kernel for stencil-free data terms and block-local proxes, Haar-l1 included (lmc_step_block.hip)
+bool block_supported(const StepArgs& a);
+hipError_t launch_step_block(const StepArgs& a, hipStream_t st);
 // split streaming variant: the same pipeline over two wave groups (lmc_step_split.hip)
 bool split_supported(const StepArgs& a);
 hipError_t launch_step_split(StepArgs a, hipStream_t st);

@@ -275,6 +275,98 @@ hipError_t launch_energies(const float* x, int64_t n_img, const EnergyArgs& E, d
   return hipGetLastError();
 }
 
+// ---- 3-level orthonormal Haar wavelet, l1 prox of the detail coefficients (BASELINE config 5's prior) -------------
+// The 3-level transform acts on independent 8 x 8 blocks: one thread = one block, all 64 values in registers,
+// in-place butterflies at strides 1, 2, 4; detail coefficients are soft-thresholded (MODE 0) or summed in absolute
+// value (MODE 1: g(x) per image).  Adjacent lanes own adjacent blocks of a block row, so each of the 8 row loads of a
+// wavefront is one contiguous 2 KiB segment (2 x float4 per lane).
+__device__ __forceinline__ float soft_thr(float v, float t) { return copysignf(fmaxf(fabsf(v) - t, 0.f), v); }
+
+template <int MODE>
+__global__ __launch_bounds__(256) void haar_l1_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W,
+                                                      int64_t n_img, float thr, double* __restrict__ val, float sigma) {
+  __shared__ double scratch[4];
+  const int nbx = W >> 3, nby = H >> 3;
+  const size_t blocks_per_img = (size_t)nbx * nby;
+  const size_t img = (size_t)H * W;
+  const size_t c = blockIdx.y;
+  double acc = 0.0;
+  for (size_t bi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; bi < blocks_per_img; bi += (size_t)gridDim.x * blockDim.x) {
+    const int by = (int)(bi / nbx), bx = (int)(bi - (size_t)by * nbx);
+    const float* src = x + c * img + (size_t)(by * 8) * W + bx * 8;
+    float v[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float4 lo = *reinterpret_cast<const float4*>(src + (size_t)r * W);
+      const float4 hi = *reinterpret_cast<const float4*>(src + (size_t)r * W + 4);
+      v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = lo.z; v[r][3] = lo.w; v[r][4] = hi.x; v[r][5] = hi.y; v[r][6] = hi.z; v[r][7] = hi.w;
+    }
+    float dsum = 0.f;
+#pragma unroll
+    for (int s = 1; s <= 4; s <<= 1) {      // forward: quads at stride s; (i, j) holds LL, (i, j+s) LH, (i+s, j) HL, (i+s, j+s) HH
+#pragma unroll
+      for (int i = 0; i < 8; i += 2 * s)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2 * s) {
+          const float a = v[i][j], b = v[i][j + s], cc = v[i + s][j], d = v[i + s][j + s];
+          const float ll = 0.5f * (a + b + cc + d), lh = 0.5f * (a - b + cc - d), hl = 0.5f * (a + b - cc - d), hh = 0.5f * (a - b - cc + d);
+          v[i][j] = ll;
+          if (MODE == 0) { v[i][j + s] = soft_thr(lh, thr); v[i + s][j] = soft_thr(hl, thr); v[i + s][j + s] = soft_thr(hh, thr); }
+          else dsum += fabsf(lh) + fabsf(hl) + fabsf(hh);
+        }
+    }
+    if (MODE == 1) { acc += (double)dsum; continue; }
+#pragma unroll
+    for (int s = 4; s >= 1; s >>= 1) {      // inverse
+#pragma unroll
+      for (int i = 0; i < 8; i += 2 * s)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2 * s) {
+          const float ll = v[i][j], lh = v[i][j + s], hl = v[i + s][j], hh = v[i + s][j + s];
+          v[i][j] = 0.5f * (ll + lh + hl + hh); v[i][j + s] = 0.5f * (ll - lh + hl - hh);
+          v[i + s][j] = 0.5f * (ll + lh - hl - hh); v[i + s][j + s] = 0.5f * (ll - lh - hl + hh);
+        }
+    }
+    float* dst = out + c * img + (size_t)(by * 8) * W + bx * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      *reinterpret_cast<float4*>(dst + (size_t)r * W) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+      *reinterpret_cast<float4*>(dst + (size_t)r * W + 4) = make_float4(v[r][4], v[r][5], v[r][6], v[r][7]);
+    }
+  }
+  if (MODE == 1) {
+    const double t = block_sum(acc, scratch);
+    if (threadIdx.x == 0) unsafeAtomicAdd(&val[c], (double)sigma * t);
+  }
+}
+
+// out = prox_{thr ||W_detail .||_1}(x)   (H, W multiples of 8)
+hipError_t launch_haar_prox(const float* x, float* out, int64_t n_img, int H, int W, float thr, hipStream_t st) {
+  const size_t nb = (size_t)(H >> 3) * (W >> 3);
+  int gx = (int)((nb + 255) / 256);
+  for (int64_t z0 = 0; z0 < n_img; z0 += 65535) {
+    const int nz = (int)((n_img - z0) < 65535 ? (n_img - z0) : 65535);
+    hipLaunchKernelGGL(haar_l1_kernel<0>, dim3(gx, nz), dim3(256), 0, st, x + z0 * (size_t)H * W, out + z0 * (size_t)H * W, H, W,
+                       (int64_t)nz, thr, nullptr, 0.f);
+  }
+  return hipGetLastError();
+}
+
+// val[i] = sigma * sum |detail coefficients of Haar(x_i)|
+hipError_t launch_haar_value(const float* x, int64_t n_img, int H, int W, float sigma, double* val, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(val, 0, sizeof(double) * n_img, st);
+  if (e != hipSuccess) return e;
+  const size_t nb = (size_t)(H >> 3) * (W >> 3);
+  int gx = (int)((nb + 255) / 256);
+  if (gx > 32) gx = 32;
+  for (int64_t z0 = 0; z0 < n_img; z0 += 65535) {
+    const int nz = (int)((n_img - z0) < 65535 ? (n_img - z0) : 65535);
+    hipLaunchKernelGGL(haar_l1_kernel<1>, dim3(gx, nz), dim3(256), 0, st, x + z0 * (size_t)H * W, nullptr, H, W, (int64_t)nz, 0.f,
+                       val + z0, sigma);
+  }
+  return hipGetLastError();
+}
+
 // ---- noise dump: the field xi[C][H][W] the step kernels draw at `iteration` -----------------
 __global__ __launch_bounds__(256) void noise_kernel(float* __restrict__ out, int C, int H, int W, uint32_t key0,
                                                     uint32_t key1, uint32_t iteration, uint32_t chain_offset) {

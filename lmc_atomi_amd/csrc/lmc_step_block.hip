@@ -1,0 +1,160 @@
+// Fused MYULA update for data terms without a stencil (identity, inpainting mask, none) and a prior whose prox is local to
+// an 8 x 8 block -- 3-level Haar-l1 (BASELINE config "inpainting mask + l1-wavelet prox"), l2, l1 or none:
+//     out = a*x - t*grad f(x) + b*prox(x) + s*xi                                   (algs.py:569)
+//
+// One thread owns one 8 x 8 block of one chain in registers: 16 float4 loads of x (the 64 lanes of a wave cover 8 image
+// rows x 512 contiguous columns), the pointwise data gradient and the Philox noise of the block (16 quads) are folded
+// into `base`, the Haar butterflies + soft threshold run in place on the copy of x, one fma per pixel and 16 float4 stores.
+// No LDS, no barrier, no halo: HBM traffic is x read once + x' written once (8 B per pixel-step); y and the mask are shared
+// by all chains and come from L2.
+#include "lmc_device.h"
+#include "lmc_launch.h"
+
+namespace lmc {
+
+#ifndef LMC_BLK_OCC
+#define LMC_BLK_OCC 2   // workgroups (4 waves each) per CU the register budget is sized for: 232 VGPRs, no scratch
+#endif
+
+__device__ __forceinline__ float soft_thr_b(float v, float thr) { return copysignf(fmaxf(fabsf(v) - thr, 0.f), v); }
+
+template <int DATA, int PRIOR>
+__global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(const StepArgs P) {
+  const int H = P.H, W = P.W;
+  const int nbx = W >> 3;
+  const uint32_t blocks_per_img = (uint32_t)nbx * (uint32_t)(H >> 3);
+  const size_t bi = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (bi >= (size_t)blocks_per_img * (size_t)P.C) return;
+  const uint32_t chain = (uint32_t)(bi / blocks_per_img);
+  const uint32_t b = (uint32_t)(bi - (size_t)chain * blocks_per_img);
+  const int by = (int)(b / (uint32_t)nbx), bx = (int)(b - (uint32_t)by * (uint32_t)nbx);
+  const size_t img = (size_t)H * W;
+  const size_t o0 = (size_t)(by * 8) * W + (size_t)bx * 8;      // offset of the block inside an image
+  const float* __restrict__ src = P.x_in + (size_t)chain * img + o0;
+  float* __restrict__ dst = P.x_out + (size_t)chain * img + o0;
+
+  float v[8][8], base[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const float4 lo = *reinterpret_cast<const float4*>(src + (size_t)r * W);
+    const float4 hi = *reinterpret_cast<const float4*>(src + (size_t)r * W + 4);
+    v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = lo.z; v[r][3] = lo.w; v[r][4] = hi.x; v[r][5] = hi.y; v[r][6] = hi.z; v[r][7] = hi.w;
+  }
+  // base = a*x - t*grad f(x)
+  const float ts = P.t * P.sigma_f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    float yv[8], mv[8];
+    if (DATA != LMC_DATA_NONE) {
+      const float4 lo = *reinterpret_cast<const float4*>(P.y + o0 + (size_t)r * W);
+      const float4 hi = *reinterpret_cast<const float4*>(P.y + o0 + (size_t)r * W + 4);
+      yv[0] = lo.x; yv[1] = lo.y; yv[2] = lo.z; yv[3] = lo.w; yv[4] = hi.x; yv[5] = hi.y; yv[6] = hi.z; yv[7] = hi.w;
+    }
+    if (DATA == LMC_DATA_MASK) {
+      const float4 lo = *reinterpret_cast<const float4*>(P.mask + o0 + (size_t)r * W);
+      const float4 hi = *reinterpret_cast<const float4*>(P.mask + o0 + (size_t)r * W + 4);
+      mv[0] = lo.x; mv[1] = lo.y; mv[2] = lo.z; mv[3] = lo.w; mv[4] = hi.x; mv[5] = hi.y; mv[6] = hi.z; mv[7] = hi.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = v[r][j];
+      float g = 0.f;                                            // grad f / sigma_f
+      if (DATA == LMC_DATA_IDENTITY) g = x - yv[j];
+      else if (DATA == LMC_DATA_MASK) g = mv[j] * fmaf(mv[j], x, -yv[j]);
+      base[r][j] = fmaf(P.a, x, -ts * g);
+    }
+  }
+  // + s * xi
+  if (P.noise_mode == LMC_NOISE_PHILOX) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float n[4];
+        quad_normals(P.key0, P.key1, P.iteration, P.chain_offset + chain, (uint32_t)(by * 2 + q) * (uint32_t)W + (uint32_t)(bx * 8 + j), n);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) base[4 * q + k][j] = fmaf(P.s, n[k], base[4 * q + k][j]);
+      }
+  } else if (P.noise_mode == LMC_NOISE_INJECTED) {
+    const float* __restrict__ nz = P.noise + (size_t)chain * img + o0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float4 lo = *reinterpret_cast<const float4*>(nz + (size_t)r * W);
+      const float4 hi = *reinterpret_cast<const float4*>(nz + (size_t)r * W + 4);
+      base[r][0] = fmaf(P.s, lo.x, base[r][0]); base[r][1] = fmaf(P.s, lo.y, base[r][1]);
+      base[r][2] = fmaf(P.s, lo.z, base[r][2]); base[r][3] = fmaf(P.s, lo.w, base[r][3]);
+      base[r][4] = fmaf(P.s, hi.x, base[r][4]); base[r][5] = fmaf(P.s, hi.y, base[r][5]);
+      base[r][6] = fmaf(P.s, hi.z, base[r][6]); base[r][7] = fmaf(P.s, hi.w, base[r][7]);
+    }
+  }
+  // v <- prox(x)
+  if (PRIOR == LMC_PRIOR_HAAR_L1) {
+    const float thr = P.prior_p0;
+#pragma unroll
+    for (int s = 1; s <= 4; s <<= 1)        // forward: (i, j) holds LL, (i, j+s) LH, (i+s, j) HL, (i+s, j+s) HH of the quad at stride s
+#pragma unroll
+      for (int i = 0; i < 8; i += 2 * s)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2 * s) {
+          const float a = v[i][j], bb = v[i][j + s], cc = v[i + s][j], d = v[i + s][j + s];
+          v[i][j] = 0.5f * (a + bb + cc + d);
+          v[i][j + s] = soft_thr_b(0.5f * (a - bb + cc - d), thr);
+          v[i + s][j] = soft_thr_b(0.5f * (a + bb - cc - d), thr);
+          v[i + s][j + s] = soft_thr_b(0.5f * (a - bb - cc + d), thr);
+        }
+#pragma unroll
+    for (int s = 4; s >= 1; s >>= 1)        // inverse
+#pragma unroll
+      for (int i = 0; i < 8; i += 2 * s)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2 * s) {
+          const float ll = v[i][j], lh = v[i][j + s], hl = v[i + s][j], hh = v[i + s][j + s];
+          v[i][j] = 0.5f * (ll + lh + hl + hh); v[i][j + s] = 0.5f * (ll - lh + hl - hh);
+          v[i + s][j] = 0.5f * (ll + lh - hl - hh); v[i + s][j + s] = 0.5f * (ll - lh - hl + hh);
+        }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float px = v[r][j];
+      if (PRIOR == LMC_PRIOR_L2) px = px * P.prior_p0;
+      else if (PRIOR == LMC_PRIOR_L1) px = soft_thr_b(px, P.prior_p0);
+      o[j] = fmaf(P.b, px, base[r][j]);
+    }
+    *reinterpret_cast<float4*>(dst + (size_t)r * W) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(dst + (size_t)r * W + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
+}
+
+bool block_supported(const StepArgs& a) {
+  if ((a.H & 7) || (a.W & 7) || a.H < 8 || a.W < 8) return false;
+  if (a.data_kind == LMC_DATA_BLUR || a.ncvx_kind != LMC_NCVX_NONE || a.extra || a.prox_ext) return false;
+  if (a.prior_kind == LMC_PRIOR_TV_ISO || a.prior_kind == LMC_PRIOR_TV_ANISO) return false;
+  if (a.tv_in || a.tv_out) return false;
+  return true;
+}
+
+template <int DATA>
+static void launch_block_data(const StepArgs& a, int nblk, hipStream_t st) {
+  switch (a.prior_kind) {
+    case LMC_PRIOR_L2: hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_L2>), dim3(nblk), dim3(256), 0, st, a); break;
+    case LMC_PRIOR_L1: hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_L1>), dim3(nblk), dim3(256), 0, st, a); break;
+    case LMC_PRIOR_HAAR_L1: hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_HAAR_L1>), dim3(nblk), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_NONE>), dim3(nblk), dim3(256), 0, st, a); break;
+  }
+}
+
+hipError_t launch_step_block(const StepArgs& a, hipStream_t st) {
+  if (!block_supported(a)) return hipErrorInvalidConfiguration;
+  const size_t nb = (size_t)(a.H >> 3) * (a.W >> 3) * (size_t)a.C;
+  const size_t nblk = (nb + 255) / 256;
+  if (nblk > 0x7fffffffu) return hipErrorInvalidConfiguration;
+  if (a.data_kind == LMC_DATA_MASK) launch_block_data<LMC_DATA_MASK>(a, (int)nblk, st);
+  else if (a.data_kind == LMC_DATA_IDENTITY) launch_block_data<LMC_DATA_IDENTITY>(a, (int)nblk, st);
+  else launch_block_data<LMC_DATA_NONE>(a, (int)nblk, st);
+  return hipGetLastError();
+}
+
+}  // namespace lmc

@@ -350,6 +350,7 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
     } else {
       px = x;
     }
+    if (A.prox_ext) px = A.prox_ext[(size_t)c.chain * H * W + gi];
     float xi = S.nz[NI];
     if (A.noise_mode == LMC_NOISE_INJECTED) xi = LD(A.noise, (size_t)c.chain * H * W + gi, (size_t)A.C * H * W, 6);
     if (A.noise_mode == LMC_NOISE_NONE) xi = 0.f;

@@ -372,7 +372,7 @@ static int stream_k(const StepArgs& a) { return a.prior_kind == LMC_PRIOR_TV_ISO
 // True if the streaming kernel covers this configuration (else the caller uses the tile kernel).
 bool stream_supported(const StepArgs& a) {
   const int NW = stream_nw(a.W);
-  if (NW == 0 || a.H < 1 || a.ncvx_kind != LMC_NCVX_NONE || a.extra) return false;
+  if (NW == 0 || a.H < 1 || a.ncvx_kind != LMC_NCVX_NONE || a.extra || a.prox_ext) return false;
   bool fits = false;
   switch (stream_k(a)) {
 #ifndef LMC_ONLY_K10

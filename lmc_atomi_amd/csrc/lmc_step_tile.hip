@@ -219,6 +219,7 @@ __global__ __launch_bounds__(kStepThreads) void myula_step_tile_kernel(const Ste
     } else {
       px = x;
     }
+    if (P.prox_ext) px = P.prox_ext[(size_t)chain * img + gi];
     float nz = xi[j];
     if (P.noise_mode == LMC_NOISE_INJECTED) nz = P.noise[(size_t)chain * img + gi];
     xout[gi] = fmaf(P.a, x, fmaf(-P.t, g, fmaf(P.b, px, P.s * nz)));

@@ -302,6 +302,39 @@ class TV(ProxOperator):
         return self._problem().eval(x, 0.0, 0.0, 1.0, float(tau))
 
 
+class WaveletL1(ProxOperator):
+    """``sigma * || detail coefficients of the 3-level orthonormal Haar transform of x ||_1`` -- the prior of BASELINE config 5
+    (build-specified; the reference has no wavelet code).  ``prox`` = W^T soft(W x, tau*sigma) on independent 8 x 8 blocks."""
+
+    def __init__(self, dims, sigma=1.0, levels=3):
+        super().__init__(None, False)
+        if levels != 3:
+            raise NotImplementedError("levels=3 (8 x 8 blocks) only")
+        self.dims = (int(dims[0]), int(dims[1]))
+        if self.dims[0] % 8 or self.dims[1] % 8:
+            raise ValueError("image sides must be multiples of 8")
+        self.sigma = float(sigma)
+        self.levels = levels
+        self._prob = None
+
+    def prior_descriptor(self):
+        return {"prior_kind": _capi.PRIOR_HAAR_L1, "prior_sigma": self.sigma}
+
+    def __call__(self, x):
+        if self._prob is None:
+            self._prob = _Problem(self.dims, prior=self.prior_descriptor())
+        _, g = self._prob.energies(x)
+        return float(g[0]) if g.numel() == 1 else (g if isinstance(x, torch.Tensor) else g.cpu().numpy())
+
+    def prox(self, x, tau):
+        xt = _dev.to_dev(x)
+        out = torch.empty_like(xt)
+        n = self.dims[0] * self.dims[1]
+        _capi.check(_dev.lib().lmc_haar_l1_prox(_dev.ptr(xt), _dev.ptr(out), xt.numel() // n, self.dims[0], self.dims[1],
+                                                self.sigma * float(tau), _dev.stream_ptr()))
+        return _dev.like_input(out, x)
+
+
 class L2_ncvx_tv(ProxOperator):
     r"""Non-log-concave data term -- drop-in for the reference's own class ``algs.L2_ncvx_tv`` (algs.py:22-291):
     ``f(x) = sigma/2 ||Op x - b||^2 - lamda * env_gamma(g)(Op2 x)``, same constructor arguments.
@@ -325,8 +358,8 @@ class L2_ncvx_tv(ProxOperator):
             raise NotImplementedError("only the isotropic branches (isotropic=True, as at prox_lmc_deconv.py:106-113) are built")
         if Op2 is not None and not isinstance(Op2, Gradient):
             raise NotImplementedError("Op2 must be a Gradient (MC-TV) or None (ME-TV)")
-        if not isinstance(Op, Convolve2D) or b is None:
-            raise NotImplementedError("Op must be a Convolve2D and b given (prox_lmc_deconv.py:106)")
+        if not isinstance(Op, (Convolve2D, Diagonal)) or b is None:
+            raise NotImplementedError("Op must be a Convolve2D (prox_lmc_deconv.py:106) or a Diagonal mask, and b given")
         self.dims = (int(dims[0]), int(dims[1]))
         self.Op2 = Op2
         self.b = b
@@ -337,8 +370,11 @@ class L2_ncvx_tv(ProxOperator):
         self._prob = None
 
     def descriptor(self):
-        return {"data_kind": _capi.DATA_BLUR, "sigma_f": self.sigma, "y": self.b, "h": self.Op.h, "offset": self.Op.offset,
-                "ncvx_kind": _capi.NCVX_MC_TV if self.Op2 is not None else _capi.NCVX_ME_TV,
+        if isinstance(self.Op, Diagonal):
+            base = {"data_kind": _capi.DATA_MASK, "sigma_f": self.sigma, "y": self.b, "mask": self.Op.d}
+        else:
+            base = {"data_kind": _capi.DATA_BLUR, "sigma_f": self.sigma, "y": self.b, "h": self.Op.h, "offset": self.Op.offset}
+        return {**base, "ncvx_kind": _capi.NCVX_MC_TV if self.Op2 is not None else _capi.NCVX_ME_TV,
                 "ncvx_lambda": self.lamda, "ncvx_gamma": self.gamma, "ncvx_niter": int(self.niter)}
 
     def _problem(self):

@@ -37,7 +37,7 @@ from numpy.random import default_rng
 
 __all__ = [
     "Convolve2D", "Gradient", "Identity", "Diagonal",
-    "L2", "L1", "L21", "TV", "L2NcvxTV",
+    "L2", "L1", "L21", "TV", "L2NcvxTV", "WaveletL1", "haar_fwd", "haar_inv", "haar_l1_prox", "haar_l1_value",
     "blur", "blur_adjoint", "grad2d", "div2d", "tv_value", "tv_prox_fgp", "fgp_betas",
     "myula", "ulpda", "myula_batched", "myula_step",
     "philox4x32_10", "philox_normals", "box_muller",
@@ -498,6 +498,69 @@ class TV(_Prox):
         return out.ravel()
 
 
+def haar_fwd(x, levels=3):
+    """Orthonormal 2-D Haar transform, `levels` levels, in place layout (Mallat): after level l the approximation
+    occupies the top-left (H/2^l, W/2^l) corner.  H and W must be multiples of 2^levels.  Build-specified prior of
+    BASELINE config 5 (the reference has no wavelet code); checked against PyWavelets (tests/golden/haar_pywt.npz)."""
+    x = np.array(x, copy=True)
+    H, W = x.shape[-2:]
+    assert H % (1 << levels) == 0 and W % (1 << levels) == 0
+    h, w = H, W
+    for _ in range(levels):
+        a = x[..., 0:h:2, 0:w:2]; b = x[..., 0:h:2, 1:w:2]; c = x[..., 1:h:2, 0:w:2]; d = x[..., 1:h:2, 1:w:2]
+        ll, lh, hl, hh = (a + b + c + d) / 2, (a - b + c - d) / 2, (a + b - c - d) / 2, (a - b - c + d) / 2
+        x[..., :h // 2, :w // 2] = ll; x[..., :h // 2, w // 2:w] = lh
+        x[..., h // 2:h, :w // 2] = hl; x[..., h // 2:h, w // 2:w] = hh
+        h, w = h // 2, w // 2
+    return x
+
+
+def haar_inv(cf, levels=3):
+    cf = np.array(cf, copy=True)
+    H, W = cf.shape[-2:]
+    h, w = H >> levels, W >> levels
+    for _ in range(levels):
+        ll = cf[..., :h, :w].copy(); lh = cf[..., :h, w:2 * w].copy(); hl = cf[..., h:2 * h, :w].copy(); hh = cf[..., h:2 * h, w:2 * w].copy()
+        cf[..., 0:2 * h:2, 0:2 * w:2] = (ll + lh + hl + hh) / 2
+        cf[..., 0:2 * h:2, 1:2 * w:2] = (ll - lh + hl - hh) / 2
+        cf[..., 1:2 * h:2, 0:2 * w:2] = (ll + lh - hl - hh) / 2
+        cf[..., 1:2 * h:2, 1:2 * w:2] = (ll - lh - hl + hh) / 2
+        h, w = 2 * h, 2 * w
+    return cf
+
+
+def haar_l1_prox(x, thr, levels=3):
+    """prox of thr * ||detail coefficients of Haar(x)||_1: soft-threshold every detail coefficient, keep the coarsest
+    approximation (orthonormal transform => exact prox)."""
+    cf = haar_fwd(x, levels)
+    H, W = cf.shape[-2:]
+    keep = cf[..., :H >> levels, :W >> levels].copy()
+    cf = np.sign(cf) * np.maximum(np.abs(cf) - thr, 0)
+    cf[..., :H >> levels, :W >> levels] = keep
+    return haar_inv(cf, levels)
+
+
+def haar_l1_value(x, levels=3):
+    cf = haar_fwd(x, levels)
+    H, W = cf.shape[-2:]
+    tot = np.sum(np.abs(cf), axis=(-2, -1))
+    return tot - np.sum(np.abs(cf[..., :H >> levels, :W >> levels]), axis=(-2, -1))
+
+
+class WaveletL1(_Prox):
+    """``sigma * ||W_detail x||_1`` with W the 3-level orthonormal Haar transform (BASELINE config 5's prior)."""
+
+    def __init__(self, dims, sigma=1.0, levels=3):
+        super().__init__(None, False)
+        self.dims, self.sigma, self.levels = tuple(dims), sigma, levels
+
+    def __call__(self, x):
+        return self.sigma * float(haar_l1_value(np.asarray(x).reshape(self.dims), self.levels))
+
+    def prox(self, x, tau):
+        return haar_l1_prox(np.asarray(x).reshape(self.dims), self.sigma * tau, self.levels).ravel()
+
+
 class L2NcvxTV(_Prox):
     """Restatement of the in-repo class ``L2_ncvx_tv`` (``algs.py:22-291``):
     ``f(x) = sigma/2||Op x - b||^2 - lamda * env_gamma(g)(Op2 x)``.
@@ -652,6 +715,8 @@ def myula_step(x, y, h, offset, sigma_f, tau, gamma, prior, xi, mask=None):
     elif kind == "tv":
         px = tv_prox_fgp(x, float(t) * prior["sigma"], prior["niter"], step=prior.get("step", 0.125),
                          betas=prior.get("betas"), momentum=prior.get("momentum", "unlocbox"))
+    elif kind == "haar":
+        px = haar_l1_prox(x, float(t) * prior["sigma"], prior.get("levels", 3))
     elif kind == "none":
         px = x
     else:

@@ -260,6 +260,32 @@ np.savez_compressed(sys.argv[2], x=x, **res)
 '''
 
 
+PYWT = r'''
+import sys, numpy as np, pywt
+x = np.load(sys.argv[1])["x"]
+res = {}
+for thr in (0.1, 2.0):
+    cf = pywt.wavedec2(x, "haar", level=3, mode="periodization")
+    new = [cf[0]] + [tuple(pywt.threshold(d, thr, "soft") for d in lev) for lev in cf[1:]]
+    res["thr_%g" % thr] = pywt.waverec2(new, "haar", mode="periodization")
+    res["val"] = np.array(sum(np.abs(d).sum() for lev in cf[1:] for d in lev))
+res["versions"] = np.array("pywt %s numpy %s" % (pywt.__version__, np.__version__))
+np.savez_compressed(sys.argv[2], x=x, **res)
+'''
+
+
+def gen_pywt(out):
+    """Independent check of the Haar-l1 prox (BASELINE config 5's prior) with PyWavelets from the conda interpreter."""
+    py39 = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py39):
+        print("skip haar_pywt.npz: no", py39)
+        return
+    img = synth_image(32, 48, 1234) + np.random.default_rng(6).normal(0, 4.0, (32, 48))
+    tmp = "/tmp/_pywt_in.npz"
+    np.savez(tmp, x=img)
+    subprocess.run([py39, "-W", "ignore", "-c", PYWT, tmp, out], check=True)
+
+
 def gen_chambolle(out):
     py39 = "/opt/conda/bin/python3.9"
     if not os.path.exists(py39):
@@ -279,6 +305,7 @@ if __name__ == "__main__":
     gen_prox(os.path.join(HERE, "prox.npz"))
     gen_algs(os.path.join(HERE, "algs.npz"))
     gen_chambolle(os.path.join(HERE, "tv_chambolle.npz"))
+    gen_pywt(os.path.join(HERE, "haar_pywt.npz"))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -1,0 +1,138 @@
+"""GPU parity of the Haar-l1 wavelet prior (BASELINE config "inpainting mask + l1-wavelet prox"): operator, energies and
+MYULA steps against the oracle (itself pinned by PyWavelets, tests/golden/haar_pywt.npz), through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import lmc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-6
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+    assert torch.cuda.is_available()
+    import lmc_atomi_amd as la
+    return la
+
+
+def test_haar_prox_matches_pywavelets_fixture(la, golden):
+    g = golden("haar_pywt.npz")
+    x = g["x"]
+    for thr in (0.1, 2.0):
+        got = la.WaveletL1(x.shape, sigma=1.0).prox(x.ravel(), thr).reshape(x.shape)
+        assert rel(got, g["thr_%g" % thr]) < TOL
+    val = la.WaveletL1(x.shape, sigma=0.7)(x.ravel())
+    assert abs(val - 0.7 * float(g["val"])) < 1e-5 * abs(val)
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (16, 64), (40, 24), (128, 520)])
+def test_haar_prox_and_value_match_oracle(la, shape):
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 30, (3,) + shape)
+    w = la.WaveletL1(shape, sigma=0.4)
+    got = w.prox(x.reshape(3, -1), 5.0).reshape(x.shape)
+    ref = O.haar_l1_prox(x, 0.4 * 5.0)
+    assert rel(got, ref) < TOL
+    assert rel(w.prox(x.reshape(3, -1), 0.0).reshape(x.shape), x) < TOL       # W^T W = I
+    vals = np.asarray(w(x.reshape(3, -1)))
+    ref_v = np.array([0.4 * O.haar_l1_value(x[i]) for i in range(3)])
+    assert np.allclose(vals, ref_v, rtol=1e-5)
+
+
+def test_haar_rejects_ragged_sizes(la):
+    with pytest.raises(ValueError):
+        la.WaveletL1((12, 16))
+    import torch
+    x = torch.zeros(12 * 16, device="cuda")
+    rc = la._dev.lib().lmc_haar_l1_prox(la._dev.ptr(x), la._dev.ptr(x), 1, 12, 16, 1.0, None)
+    assert rc == -2  # LMC_E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("data,shape", [("mask", (64, 64)), ("mask", (24, 520)), ("blur", (48, 128)), ("identity", (16, 16))])
+def test_myula_steps_haar_prior(la, data, shape):
+    """The inpainting configuration: f = sigma/2 ||M x - y||^2, g = lam ||W_detail x||_1; every step kernel."""
+    sigma, lam = 0.75, 2.0
+    gamma, tau = sigma ** 2, 0.2 * sigma ** 2
+    rng = np.random.default_rng(5)
+    C, nit = 3, 3
+    img = np.zeros(shape)
+    img[shape[0] // 4:shape[0] // 2, shape[1] // 5:shape[1] // 2] = 180.0
+    img += np.linspace(0, 40, shape[1])[None, :]
+    mask, h, off = None, None, None
+    if data == "mask":
+        mask = (rng.uniform(size=shape) < 0.6).astype(np.float64)
+        y = mask * (img + rng.normal(0, sigma, shape))
+        pf = la.L2(Op=la.Diagonal(mask, dims=shape), b=y, sigma=1 / sigma ** 2, dims=shape)
+    elif data == "blur":
+        h, off = np.ones((5, 5)) / 25, (2, 2)
+        y = O.blur(img, h, off) + rng.normal(0, sigma, shape)
+        pf = la.L2(Op=la.Convolve2D(shape, h, offset=off), b=y, sigma=1 / sigma ** 2)
+    else:
+        y = img + rng.normal(0, sigma, shape)
+        pf = la.L2(b=y, sigma=1 / sigma ** 2, dims=shape)
+    pg = la.WaveletL1(shape, sigma=lam)
+    x0 = img[None] + rng.normal(0, 10, (C,) + shape)
+    noise = rng.standard_normal((nit, C) + shape)
+    prior = {"kind": "haar", "sigma": lam, "t": gamma}
+    outs = {}
+    for variant in ("tile", "point", "auto") + (("block",) if data != "blur" else ()):
+        la.set_step_variant(variant)
+        smp = la.MYULASampler(pf, pg, shape, n_chains=C, tau=tau, gamma=gamma, noise="injected")
+        smp.set_state(x0)
+        x = x0.copy()
+        for it in range(nit):
+            smp.step(1, noise=noise[it:it + 1])
+            x = O.myula_step(x, y, h, off, 1 / sigma ** 2, tau, gamma, prior, noise[it], mask=mask)
+            got = smp.get_state().cpu().numpy()
+            assert rel(got, x) < TOL * (it + 1), (variant, it, rel(got, x))
+        f, g = smp.energies()
+        gref = np.array([lam * O.haar_l1_value(x[i]) for i in range(C)])
+        assert np.allclose(g.cpu().numpy(), gref, rtol=2e-5), variant
+        assert smp.kernel_name == {"tile": "myula_step_tile_kernel", "point": "myula_step_point_kernel", "block": "myula_step_block_kernel",
+                                   "auto": "myula_step_split_kernel" if data == "blur" else "myula_step_block_kernel"}[variant]
+        outs[variant] = got
+        smp.close()
+    la.set_step_variant("auto")
+    assert rel(outs["tile"], outs["auto"]) < TOL
+
+
+def test_haar_prior_many_iterations_philox_and_moments(la):
+    """Philox noise, several iterations per call, moments: the two-launch (prox, step) sequence keeps the iteration
+    counter, the ping-pong buffers and the accumulators consistent."""
+    shape = (32, 64)
+    rng = np.random.default_rng(8)
+    mask = (rng.uniform(size=shape) < 0.5).astype(np.float64)
+    y = mask * rng.uniform(0, 255, shape)
+    pf = la.L2(Op=la.Diagonal(mask, dims=shape), b=y, sigma=1.5, dims=shape)
+    pg = la.WaveletL1(shape, sigma=1.0)
+    kw = dict(n_chains=4, tau=0.1, gamma=0.5, seed=21, moments=True)
+    a = la.MYULASampler(pf, pg, shape, **kw)
+    b = la.MYULASampler(pf, pg, shape, **kw)
+    a.step(7)
+    xs = []
+    for _ in range(7):
+        b.step(1)
+        xs.append(b.get_state().cpu().numpy().astype(np.float64))
+    np.testing.assert_array_equal(a.get_state().cpu().numpy(), b.get_state().cpu().numpy())
+    s1, s2, n = a.moments()
+    assert n == 7 * 4
+    ref = np.sum(np.concatenate(xs, axis=0), axis=0)
+    assert rel(s1.cpu().numpy(), ref) < 1e-6
+    # one step against the oracle with the sampler's own noise field
+    c = la.MYULASampler(pf, pg, shape, **kw)
+    x0 = c.get_state().cpu().numpy().astype(np.float64)
+    xi = c.noise_field(0).cpu().numpy().astype(np.float64)
+    c.step(1)
+    ref1 = O.myula_step(x0, y, None, None, 1.5, 0.1, 0.5, {"kind": "haar", "sigma": 1.0, "t": 0.5}, xi, mask=mask)
+    assert rel(c.get_state().cpu().numpy(), ref1) < 5e-6
+    for s in (a, b, c):
+        s.close()

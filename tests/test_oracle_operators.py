@@ -131,3 +131,20 @@ def test_philox_normals_statistics_and_sharding_invariance():
     np.testing.assert_array_equal(part, n[5:7])
     other = O.philox_normals(seed=7, iteration=4, chain_ids=np.arange(8), H=30, W=64)
     assert np.abs(other - n).max() > 1
+
+
+def test_haar_l1_prox_matches_pywavelets(golden):
+    g = golden("haar_pywt.npz")
+    x = g["x"]
+    for thr in (0.1, 2.0):
+        np.testing.assert_allclose(O.haar_l1_prox(x, thr), g["thr_%g" % thr], rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(O.haar_l1_value(x), float(g["val"]), rtol=1e-12)
+    # orthonormal: perfect reconstruction and norm preservation
+    np.testing.assert_allclose(O.haar_inv(O.haar_fwd(x)), x, atol=1e-12)
+    assert abs(np.linalg.norm(O.haar_fwd(x)) - np.linalg.norm(x)) < 1e-10
+    # prox optimality: 0 in (p - x) + thr * d||W_d p||_1  <=>  W(p - x) = -thr*sign(W p) on nonzero detail coefficients
+    p = O.haar_l1_prox(x, 2.0)
+    cp, cx = O.haar_fwd(p), O.haar_fwd(x)
+    nz = np.abs(cp) > 1e-12
+    nz[:4, :6] = False
+    np.testing.assert_allclose((cx - cp)[nz], 2.0 * np.sign(cp[nz]), atol=1e-10)
