@@ -249,7 +249,8 @@ int lmc_sampler_set_steps(lmc_sampler* s, float tau, float mu);
 /* Step-kernel variant used by lmc_sampler_step / lmc_fused_eval: 0 = auto (default), 1 = LDS-tiled,
  * 2 = streaming register pipeline (one wave group), 3 = the same pipeline split over two wave groups,
  * 4 = HBM-bound tiled kernel for closed-form priors, 5 = register-block kernel (stencil-free data term, prox local to
- * 8 x 8 blocks: Haar-l1 / l2 / l1 / none; H, W multiples of 8).  Returns the previous setting (>= 0) or a negative lmc_status.
+ * 8 x 8 blocks: Haar-l1 / l2 / l1 / none; H, W multiples of 8), 6 = barrier-free row streaming (separable blur + closed-form
+ * prior, W <= 512, W % 4 == 0).  Returns the previous setting (>= 0) or a negative lmc_status.
  * Both variants compute the same update; the switch exists for A/B tests and profiles. */
 int lmc_set_step_variant(int32_t variant);
 

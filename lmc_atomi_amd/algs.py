@@ -418,9 +418,9 @@ def MoreauYosidaUnadjustedLangevin(proxf, proxg, x0, tau=None, gamma=.1, epsg=1.
 
 
 def set_step_variant(variant="auto"):
-    """Select the step-kernel variant ('auto' | 'tile' | 'stream' | 'split' | 'point' | 'block'); returns the previous one.
+    """Select the step-kernel variant ('auto' | 'tile' | 'stream' | 'split' | 'point' | 'block' | 'rows'); returns the previous one.
     All compute the same update -- for A/B tests and profiles."""
-    names = ["auto", "tile", "stream", "split", "point", "block"]
+    names = ["auto", "tile", "stream", "split", "point", "block", "rows"]
     prev = _dev.lib().lmc_set_step_variant(names.index(variant))
     if prev < 0:
         _capi.check(prev)

@@ -212,7 +212,7 @@ void sanitize_pointers(lmc::StepArgs& A) {
   if (!A.noise) A.noise = A.x_in;
 }
 
-int g_variant = 0;  // 0 auto, 1 tile, 2 stream, 3 split, 4 point, 5 block
+int g_variant = 0;  // 0 auto, 1 tile, 2 stream, 3 split, 4 point, 5 block, 6 rows
 
 // Picks the step-kernel variant.  auto: the split streaming pipeline (two wave groups, 4 waves/SIMD) when
 // it covers the configuration (W <= 512, separable blur <= 7x7, supported K), else the LDS-tiled kernel.
@@ -233,6 +233,12 @@ hipError_t launch_step(const lmc::StepArgs& A_in, hipStream_t st, const char** n
     A.prior_kind = LMC_PRIOR_NONE;
     A.prox_ext = pxbuf;
   }
+  // separable blur + closed-form prior (no TV pipeline): barrier-free row streaming, one wave per band of rows
+  if ((v == 0 || v == 6) && lmc::rows_supported(A)) {
+    if (name) *name = "myula_step_rows_kernel";
+    return lmc::launch_step_rows(A, st);
+  }
+  if (v == 6) return hipErrorInvalidConfiguration;
   // auto: split pipeline when it covers the configuration (W <= 512); for wider images the tiled kernels:
   // "point" for closed-form priors with a separable blur, else the general LDS-tiled kernel
   if (v == 0) v = lmc::split_supported(A) ? 3 : (lmc::point_supported(A) ? 4 : (lmc::stream_supported(A) ? 2 : 1));
@@ -908,8 +914,8 @@ int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_lau
 const char* lmc_sampler_kernel_name(const lmc_sampler* s) { return s ? s->kernel_name.c_str() : ""; }
 
 int lmc_set_step_variant(int32_t variant) {
-  if (variant < 0 || variant > 5)
-    return fail(LMC_E_INVALID, "variant must be 0 (auto), 1 (tile), 2 (stream), 3 (split), 4 (point) or 5 (block)");
+  if (variant < 0 || variant > 6)
+    return fail(LMC_E_INVALID, "variant must be 0 (auto), 1 (tile), 2 (stream), 3 (split), 4 (point), 5 (block) or 6 (rows)");
   const int prev = g_variant;
   g_variant = variant;
   return prev;

@@ -191,8 +191,58 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ 
   unsafeAtomicAdd(&s2[p], b);
 }
 
+// 4 pixels per thread (b128 loads), chains unrolled by 8: 8 independent 16-byte loads in flight per lane.
+__global__ __launch_bounds__(256) void moments4_kernel(const float* __restrict__ x, int C, size_t img, int seg_len,
+                                                       double* __restrict__ s1, double* __restrict__ s2) {
+  const size_t p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int c0 = blockIdx.y * seg_len;
+  const int c1 = p < img ? min(C, c0 + seg_len) : c0;      // threads past the image keep zeros (they still reach the barrier)
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+  const float* __restrict__ src = x + p;
+  int c = c0;
+  for (; c + 8 <= c1; c += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(c + u) * img);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double d0 = v[u].x, d1 = v[u].y, d2 = v[u].z, d3 = v[u].w;
+      a[0] += d0; a[1] += d1; a[2] += d2; a[3] += d3;
+      b[0] = fma(d0, d0, b[0]); b[1] = fma(d1, d1, b[1]); b[2] = fma(d2, d2, b[2]); b[3] = fma(d3, d3, b[3]);
+    }
+  }
+  for (; c < c1; ++c) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * img);
+    const double d0 = v.x, d1 = v.y, d2 = v.z, d3 = v.w;
+    a[0] += d0; a[1] += d1; a[2] += d2; a[3] += d3;
+    b[0] = fma(d0, d0, b[0]); b[1] = fma(d1, d1, b[1]); b[2] = fma(d2, d2, b[2]); b[3] = fma(d3, d3, b[3]);
+  }
+  // lane-contiguous atomics (a wave's 64 adds hit 512 contiguous bytes): transpose the 4-pixel groups through LDS
+  __shared__ double sh[2][4 * 256];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { sh[0][4 * threadIdx.x + k] = a[k]; sh[1][4 * threadIdx.x + k] = b[k]; }
+  __syncthreads();
+  const size_t pb = (size_t)blockIdx.x * blockDim.x * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const size_t q = pb + (size_t)k * 256 + threadIdx.x;
+    if (q < img) {
+      unsafeAtomicAdd(&s1[q], sh[0][k * 256 + threadIdx.x]);
+      unsafeAtomicAdd(&s2[q], sh[1][k * 256 + threadIdx.x]);
+    }
+  }
+}
+
 hipError_t launch_moments(const float* x, int C, int H, int W, double* s1, double* s2, hipStream_t st) {
   const size_t img = (size_t)H * W;
+  if ((img & 3) == 0) {
+    const int gx4 = (int)((img / 4 + 255) / 256);
+    int nseg = 1;
+    while ((size_t)gx4 * nseg < 2048 && nseg * 16 <= C) nseg *= 2;
+    const int seg_len = (C + nseg - 1) / nseg;
+    hipLaunchKernelGGL(moments4_kernel, dim3(gx4, nseg), dim3(256), 0, st, x, C, img, seg_len, s1, s2);
+    return hipGetLastError();
+  }
   const int gx = (int)((img + 255) / 256);
   int nseg = 1;
   while ((size_t)gx * nseg < 2048 && nseg * 8 <= C) nseg *= 2;

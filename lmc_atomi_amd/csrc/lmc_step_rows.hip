@@ -1,0 +1,282 @@
+// Fused MYULA update for a separable blur data term and a prior without a stencil (l2, l1, none, or a prox computed by a
+// preceding launch):   out = a*x - t*sigma_f H^T(Hx - y) + b*prox(x) + s*xi        (algs.py:569, grad algs.py:283-284)
+//
+// Barrier-free row streaming.  ONE wave owns the full width of a band of rows of one chain: lane l holds PXL = 4 or 8
+// consecutive pixels of the row (W <= 64*PXL), so the zero boundary of the "same" convolution is the wave's own edge and no
+// wave ever talks to another one -- no LDS, no __syncthreads.  The wave walks down its band one input row per step:
+//   x row i --h-blur--> scattered into KT residual accumulators (rows i-HW..i+HW)
+//   residual row i-HW complete: R = Hx - y (zero outside the image) --h-adjoint--> scattered into KT gradient accumulators
+//   gradient row o = i-(KT-1) complete: combine with x[o] (still in the register ring), prox, Philox noise, store.
+// Horizontal neighbours: 2*HW wave-shift DPP moves per pass for PXL pixels.  All ring slots are (row & 7) with the row loop
+// unrolled by 8, so every index is a compile-time constant and the rings live in VGPRs without rotation moves.
+// Bands start KT-1 rows early (recompute instead of exchange); HBM traffic = x read once (+ band overlap) + x' written once.
+#include "lmc_device.h"
+#include "lmc_launch.h"
+
+#include <cstdlib>
+
+namespace lmc {
+
+#ifndef LMC_ROWS_PF
+#define LMC_ROWS_PF 4
+#endif
+
+template <int PXL, int KT>
+struct RowsGeom {
+  static constexpr int HW = (KT - 1) / 2;         // taps are centred: window c-HW .. c+HW
+  static constexpr int LAG = KT - 1;              // output row = input row - LAG
+  static constexpr int PF = 8 - LAG < LMC_ROWS_PF ? 8 - LAG : LMC_ROWS_PF;   // x rows fetched ahead; PF + LAG <= 8 keeps row o's slot intact
+};
+
+template <int PXL>
+__device__ __forceinline__ void rows_load(float (&dst)[PXL], const float* __restrict__ row, int c0, int W, bool rowok) {
+#pragma unroll
+  for (int g = 0; g < PXL / 4; ++g) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rowok && c0 + 4 * g < W) v = *reinterpret_cast<const float4*>(row + c0 + 4 * g);
+    dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
+  }
+}
+
+template <int PXL, int KT>
+__global__ __launch_bounds__(256, PXL == 8 ? 2 : 3) void myula_step_rows_kernel(const StepArgs P, const int band_rows, const int nbands) {
+  using Gm = RowsGeom<PXL, KT>;
+  constexpr int HW = Gm::HW, LAG = Gm::LAG, PF = Gm::PF;
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gw >= P.C * nbands) return;                       // whole waves leave; nothing below synchronises
+  const int chain = gw / nbands, band = gw - chain * nbands;
+  const int H = P.H, W = P.W;
+  const int r0 = band * band_rows, r1 = min(r0 + band_rows, H);
+  const int c0 = lane * PXL;
+  const size_t img = (size_t)H * W;
+  const float* __restrict__ xin = P.x_in + (size_t)chain * img;
+  float* __restrict__ xout = P.x_out + (size_t)chain * img;
+  const float* __restrict__ uv = P.blur.h;              // u[0..KT) then v[0..KT) at h[kMaxBlur..], centred, zero padded
+  const int i_first = r0 - LAG;
+
+  // 8 px / lane: the 32 normals of a quad row-group wait in a wave-private LDS slab (each lane reads back only what it
+  // wrote, so no barrier) instead of 32 VGPRs -- the register file is the limit at 2 waves / SIMD.
+  constexpr bool kNzLds = PXL == 8;
+  __shared__ float nz_lds[kNzLds ? 4 * PXL * 4 * 64 : 1];
+  float* const nzw = nz_lds + (kNzLds ? (threadIdx.x >> 6) * PXL * 4 * 64 + lane : 0);
+  float xr[8][PXL], A[8][PXL], G[8][PXL], nz[kNzLds ? 1 : PXL][4], yq[2][PXL];
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int k = 0; k < PXL; ++k) { xr[s][k] = 0.f; A[s][k] = 0.f; G[s][k] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < (kNzLds ? 1 : PXL); ++k) nz[k][0] = nz[k][1] = nz[k][2] = nz[k][3] = 0.f;
+  if constexpr (kNzLds) {
+#pragma unroll
+    for (int k = 0; k < PXL * 4; ++k) nzw[k * 64] = 0.f;
+  }
+
+  // prime the x ring: rows i_first .. i_first + PF - 1   (i_first = r0 - LAG with r0 % 8 == 0, so slot = (8 - LAG + p) & 7)
+  static_for<0, PF>([&](auto pp) {
+    constexpr int p = decltype(pp)::value;
+    const int i = i_first + p;
+    rows_load<PXL>(xr[(8 - LAG + p) & 7], xin + (size_t)max(i, 0) * W, c0, W, i >= 0 && i < H);
+  });
+
+  {   // observation row of the first step (row i_first - HW; J = 8 - LAG is even)
+    const int r = i_first - HW;
+    rows_load<PXL>(yq[0], P.y + (size_t)max(r, 0) * W, c0, W, r >= 0 && r < H);
+  }
+
+  // One step = input row i = base + J (J = i & 7 is a compile-time constant: every ring slot below is static).
+  // No step is conditional, so a ring slot is dead between its last read and the assignment that restarts it.
+  auto step = [&](auto jj, const int base) __attribute__((always_inline)) {
+    constexpr int J = decltype(jj)::value;
+    const int i = base + J;
+      // (0) the observation row of the NEXT step, so that its latency hides behind this step's arithmetic
+      rows_load<PXL>(yq[(J + 1) & 1], P.y + (size_t)min(max(i + 1 - HW, 0), H - 1) * W, c0, W, i + 1 - HW >= 0 && i + 1 - HW < H);
+      // (1) horizontal blur of x row i
+      float hx[PXL];
+      {
+        float e[PXL + 2 * HW];
+#pragma unroll
+        for (int m = 0; m < HW; ++m) e[m] = dpp_from_left(xr[J][PXL - HW + m], 0.f);
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) e[HW + k] = xr[J][k];
+#pragma unroll
+        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_from_right(xr[J][m], 0.f);
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) {
+          float acc = uv[kMaxBlur] * e[k + 2 * HW];
+#pragma unroll
+          for (int b = 1; b < KT; ++b) acc = fmaf(uv[kMaxBlur + b], e[k + 2 * HW - b], acc);
+          hx[k] = acc;
+        }
+      }
+      // (2) scatter into the residual accumulators of rows i-HW .. i+HW (the last one starts here)
+      static_for<0, KT>([&](auto aa) {
+        constexpr int a = decltype(aa)::value;
+        constexpr int s = (J + a - HW + 8) & 7;
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) A[s][k] = (a == KT - 1) ? uv[a] * hx[k] : fmaf(uv[a], hx[k], A[s][k]);
+      });
+      // (3) residual row r = i - HW is complete
+      const int r = i - HW;
+      constexpr int sr = (J - HW + 8) & 7;
+      float R[PXL];
+      {
+        const bool rowok = r >= 0 && r < H;
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) R[k] = (rowok && c0 + (k & ~3) < W) ? A[sr][k] - yq[J & 1][k] : 0.f;
+      }
+      // (4) horizontal adjoint of the residual row
+      float hr[PXL];
+      {
+        float e[PXL + 2 * HW];
+#pragma unroll
+        for (int m = 0; m < HW; ++m) e[m] = dpp_from_left(R[PXL - HW + m], 0.f);
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) e[HW + k] = R[k];
+#pragma unroll
+        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_from_right(R[m], 0.f);
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) {
+          float acc = uv[kMaxBlur] * e[k];
+#pragma unroll
+          for (int b = 1; b < KT; ++b) acc = fmaf(uv[kMaxBlur + b], e[k + b], acc);
+          hr[k] = acc;
+        }
+      }
+      // (5) scatter into the gradient accumulators of rows r+HW .. r-HW, i.e. i .. i-LAG (the first one starts here)
+      static_for<0, KT>([&](auto aa) {
+        constexpr int a = decltype(aa)::value;
+        constexpr int s = (J - a + 8) & 7;
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) G[s][k] = (a == 0) ? uv[0] * hr[k] : fmaf(uv[a], hr[k], G[s][k]);
+      });
+      // (6) output row o = i - LAG
+      const int o = i - LAG;
+      constexpr int so = (J - LAG + 8) & 7;
+      if (o >= r0 && o < r1) {
+        if constexpr (((J - LAG + 8) & 3) == 0) {       // first row of a Philox quad (r0 % 8 == 0)
+          if (P.noise_mode == LMC_NOISE_PHILOX) {
+#pragma unroll
+            for (int k = 0; k < PXL; ++k) {
+              float n4[4];
+              quad_normals(P.key0, P.key1, P.iteration, P.chain_offset + (uint32_t)chain,
+                           (uint32_t)(o >> 2) * (uint32_t)W + (uint32_t)(c0 + k), n4);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                if constexpr (kNzLds) nzw[(q * PXL + k) * 64] = n4[q];
+                else nz[k][q] = n4[q];
+              }
+            }
+          }
+        }
+        constexpr int jq = (J - LAG + 8) & 3;
+        const size_t go = (size_t)o * W;
+#pragma unroll
+        for (int g = 0; g < PXL / 4; ++g) {
+          if (c0 + 4 * g < W) {
+            float xi[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if constexpr (kNzLds) xi[q] = nzw[(jq * PXL + 4 * g + q) * 64];
+              else xi[q] = nz[4 * g + q][jq];
+            }
+            if (P.noise_mode == LMC_NOISE_INJECTED) {
+              const float4 v = *reinterpret_cast<const float4*>(P.noise + (size_t)chain * img + go + c0 + 4 * g);
+              xi[0] = v.x; xi[1] = v.y; xi[2] = v.z; xi[3] = v.w;
+            }
+            float pe[4] = {0.f, 0.f, 0.f, 0.f}, ex[4] = {0.f, 0.f, 0.f, 0.f};
+            if (P.prox_ext) {
+              const float4 v = *reinterpret_cast<const float4*>(P.prox_ext + (size_t)chain * img + go + c0 + 4 * g);
+              pe[0] = v.x; pe[1] = v.y; pe[2] = v.z; pe[3] = v.w;
+            }
+            if (P.extra) {
+              const float4 v = *reinterpret_cast<const float4*>(P.extra + (size_t)chain * img + go + c0 + 4 * g);
+              ex[0] = v.x; ex[1] = v.y; ex[2] = v.z; ex[3] = v.w;
+            }
+            float ov[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float x = xr[so][4 * g + q];
+              float gr = P.sigma_f * G[so][4 * g + q];
+              if (P.extra) gr = fmaf(P.extra_coef, x - ex[q], gr);
+              float px = x;
+              if (P.prior_kind == LMC_PRIOR_L2) px = x * P.prior_p0;
+              else if (P.prior_kind == LMC_PRIOR_L1) px = copysignf(fmaxf(fabsf(x) - P.prior_p0, 0.f), x);
+              if (P.prox_ext) px = pe[q];
+              ov[q] = fmaf(P.a, x, fmaf(-P.t, gr, fmaf(P.b, px, P.s * xi[q])));
+            }
+            *reinterpret_cast<float4*>(xout + go + c0 + 4 * g) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+          }
+        }
+      }
+      // (7) fetch x row i + PF into the slot row i + PF - 8 has just left (its last use was step (6) above at the latest)
+      {
+        const int ip = i + PF;
+        rows_load<PXL>(xr[(J + PF) & 7], xin + (size_t)min(max(ip, 0), H - 1) * W, c0, W, ip >= 0 && ip < H);
+      }
+  };
+  const int r1r = (r1 + 7) & ~7;
+  static_for<8 - LAG, 8>([&](auto jj) { step(jj, r0 - 8); });                    // fill: rows r0-LAG .. r0-1, nothing to emit
+  for (int base = r0; base < r1r; base += 8) static_for<0, 8>([&](auto jj) { step(jj, base); });
+  static_for<0, LAG>([&](auto jj) { step(jj, r1r); });                          // drain: the last LAG output rows
+}
+
+bool separate_blur_taps(const BlurTaps& T, float* u, float* v);  // lmc_step_stream.hip
+
+// Centred taps: the window of a kh-tap kernel with offset oy is rows r+oy-kh+1 .. r+oy; with KT = 2*HW+1 taps centred
+// on r that is u'[a + HW - oy] = u[a], which needs 0 <= HW - oy and kh + HW - oy <= KT.
+static bool rows_centre(const float* u, int n, int off, int KT, float* out) {
+  const int HW = (KT - 1) / 2, sh = HW - off;
+  if (sh < 0 || n + sh > KT) return false;
+  for (int i = 0; i < KT; ++i) out[i] = 0.f;
+  for (int i = 0; i < n; ++i) out[i + sh] = u[i];
+  return true;
+}
+
+static int rows_kt(const StepArgs& a, float* uc, float* vc) {
+  float u[kMaxBlur] = {0}, v[kMaxBlur] = {0};
+  if (a.blur.kh > 7 || a.blur.kw > 7 || !separate_blur_taps(a.blur, u, v)) return 0;
+  for (int KT = 5; KT <= 7; KT += 2)
+    if (rows_centre(u, a.blur.kh, a.blur.oy, KT, uc) && rows_centre(v, a.blur.kw, a.blur.ox, KT, vc)) return KT;
+  return 0;
+}
+
+bool rows_supported(const StepArgs& a) {
+  if (a.data_kind != LMC_DATA_BLUR || a.ncvx_kind != LMC_NCVX_NONE) return false;
+  if (a.prior_kind != LMC_PRIOR_NONE && a.prior_kind != LMC_PRIOR_L2 && a.prior_kind != LMC_PRIOR_L1) return false;
+  if (a.tv_in || a.tv_out) return false;
+  if ((a.W & 3) || a.W > 512 || a.W < 4 || a.H < 1) return false;
+  float uc[kMaxBlur], vc[kMaxBlur];
+  const int KT = rows_kt(a, uc, vc);
+  if (KT == 0) return false;
+  if (KT == 7 && a.W > 256) return false;      // 7 taps x 8 pixels per lane does not fit the register file at 2 waves / SIMD
+  return true;
+}
+
+hipError_t launch_step_rows(StepArgs a, hipStream_t st) {
+  if (!rows_supported(a)) return hipErrorInvalidConfiguration;
+  float uc[kMaxBlur] = {0}, vc[kMaxBlur] = {0};
+  const int KT = rows_kt(a, uc, vc);
+  for (int i = 0; i < kMaxBlur; ++i) { a.blur.h[i] = i < KT ? uc[i] : 0.f; a.blur.h[kMaxBlur + i] = i < KT ? vc[i] : 0.f; }
+  // bands: enough waves to fill 1024 SIMDs a few times over, but >= 16 rows each (a band recomputes KT-1 rows at each end)
+  static const int env_band = [] { const char* e = getenv("LMC_ROWS_BAND"); return e ? atoi(e) : 0; }();
+  int band = env_band > 0 ? env_band : 0;
+  if (band == 0) {
+    const int want = (4096 + a.C - 1) / a.C;                         // bands per chain for ~4 waves per SIMD
+    band = (a.H + want - 1) / want;
+    if (band < 16) band = 16;
+  }
+  band = (band + 7) & ~7;
+  const int nbands = (a.H + band - 1) / band;
+  const long long waves = (long long)a.C * nbands;
+  const int nblk = (int)((waves + 3) / 4);
+  if (a.W <= 256) {
+    if (KT == 5) hipLaunchKernelGGL((myula_step_rows_kernel<4, 5>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+    else hipLaunchKernelGGL((myula_step_rows_kernel<4, 7>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+  } else {
+    hipLaunchKernelGGL((myula_step_rows_kernel<8, 5>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace lmc

@@ -98,7 +98,7 @@ def test_myula_steps_haar_prior(la, data, shape):
         gref = np.array([lam * O.haar_l1_value(x[i]) for i in range(C)])
         assert np.allclose(g.cpu().numpy(), gref, rtol=2e-5), variant
         assert smp.kernel_name == {"tile": "myula_step_tile_kernel", "point": "myula_step_point_kernel", "block": "myula_step_block_kernel",
-                                   "auto": "myula_step_split_kernel" if data == "blur" else "myula_step_block_kernel"}[variant]
+                                   "auto": "myula_step_rows_kernel" if data == "blur" else "myula_step_block_kernel"}[variant]
         outs[variant] = got
         smp.close()
     la.set_step_variant("auto")
@@ -136,3 +136,44 @@ def test_haar_prior_many_iterations_philox_and_moments(la):
     assert rel(c.get_state().cpu().numpy(), ref1) < 5e-6
     for s in (a, b, c):
         s.close()
+
+
+@pytest.mark.parametrize("kind,niter_in", [("mc", 0), ("me", 8), ("me", 30)])
+def test_config5_mask_haar_with_nonconvex_term(la, kind, niter_in):
+    """Bernoulli(0.5) mask from default_rng(7), Haar-l1 prox (threshold 0.3*gamma) and the L2_ncvx_tv-style
+    Moreau-difference term (lamda = 0.3, gamma = 15; algs.py:270-291) -- one MYULA step per iteration against
+    x' = (1 - tau/gamma) x - tau grad f(x) + tau/gamma prox(x) + sqrt(2 tau) xi with the oracle's class gradient."""
+    shape = (64, 128)
+    sigma, lam = 0.75, 0.3
+    gamma, tau = sigma ** 2, 0.2 * sigma ** 2
+    mask = (np.random.default_rng(7).uniform(size=shape) < 0.5).astype(np.float64)
+    rng = np.random.default_rng(1)
+    img = np.zeros(shape); img[10:40, 30:90] = 200.0
+    y = mask * (img + rng.normal(0, sigma, shape))
+    C, nit = 2, 3
+    x0 = img[None] + rng.normal(0, 12, (C,) + shape)
+    noise = rng.standard_normal((nit, C) + shape)
+    kw = dict(dims=shape, b=y.ravel(), sigma=1 / sigma ** 2, lamda=0.3, gamma=15.0, isotropic=True, niter=max(niter_in, 1))
+    if kind == "mc":
+        pf = la.L2_ncvx_tv(Op=la.Diagonal(mask, dims=shape), Op2=la.Gradient(shape), **kw)
+        of = O.L2NcvxTV(Op=O.Diagonal(mask), Op2=O.Gradient(shape), **kw)
+    else:
+        pf = la.L2_ncvx_tv(Op=la.Diagonal(mask, dims=shape), **kw)
+        of = O.L2NcvxTV(Op=O.Diagonal(mask), **kw)
+    pg = la.WaveletL1(shape, sigma=lam)
+    for variant in ("tile", "auto"):
+        la.set_step_variant(variant)
+        smp = la.MYULASampler(pf, pg, shape, n_chains=C, tau=tau, gamma=gamma, noise="injected")
+        smp.set_state(x0)
+        x = x0.copy()
+        for it in range(nit):
+            smp.step(1, noise=noise[it:it + 1])
+            g = np.stack([of.grad(x[c].ravel().copy()).reshape(shape) for c in range(C)])
+            x = (1 - tau / gamma) * x - tau * g + (tau / gamma) * O.haar_l1_prox(x, gamma * lam) + np.sqrt(2 * tau) * noise[it]
+            got = smp.get_state().cpu().numpy()
+            assert rel(got, x) < 5e-6 * (it + 1), (variant, it, rel(got, x))
+        f, gval = smp.energies()
+        fref = np.array([of(x[c].ravel()) for c in range(C)])
+        assert np.allclose(f.cpu().numpy(), fref, rtol=5e-5), (variant, f.cpu().numpy(), fref)
+        smp.close()
+    la.set_step_variant("auto")
