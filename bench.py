@@ -170,9 +170,10 @@ def main():
         # only quoted when the profile is of this kernel on this workload
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_split.json")))
-            if (H, W, C, args.tv_iters, args.prior, args.data) == (512, 512, 1024, 10, "tv", "blur") and "split" in smp.kernel_name:
-                traffic = tj["traffic_bytes_per_launch"]
+            want = {"H": H, "W": W, "C": C, "prior": args.prior, "data": args.data, "tv_iters": args.tv_iters, "ncvx": args.ncvx}
+            for ent in json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["entries"]:
+                if ent["workload"] == want and ent["kernel"] == smp.kernel_name:
+                    traffic = ent["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
         value = C * world * args.steps / elapsed

@@ -190,6 +190,17 @@ typedef struct lmc_myula_config {
 int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out);
 void lmc_sampler_destroy(lmc_sampler* s);
 
+/* MYMALA -- the Metropolis-adjusted MYULA of prox_lmc.py:134-158 at image scale, every chain at once, same configuration
+ * struct.  Per iteration and chain: x' = m(x) + sqrt(2 tau) xi (the MYULA move, :150); accepted with probability
+ * min(1, pi(x') q(x|x') / (pi(x) q(x'|x))), pi = exp(-f - g), q(.|b) = N(m(b), 2 tau I) (:139-143,151-154); u ~ U(0,1) from
+ * Philox (ctr = (0, iteration, global chain id, 0x4C4D4302), key = seed).  A rejected chain keeps its state, which is
+ * counted again by the moment accumulators (the reference's toy version drops rejected iterations from its output list).
+ * All lmc_sampler_* calls apply; n_chains <= 65535. */
+int lmc_mymala_create(const lmc_myula_config* cfg, lmc_sampler** out);
+/* accepted_dev [n_chains] uint64: accepted proposals so far; last_log_alpha_dev [n_chains] f64 (nullable): log acceptance
+ * ratio of the latest iteration.  Device buffers. */
+int lmc_sampler_get_acceptance(lmc_sampler* s, uint64_t* accepted_dev, double* last_log_alpha_dev, void* stream);
+
 /* x_dev: [n_chains][H][W].  x0 of algs.py:559 (copied). */
 int lmc_sampler_set_state(lmc_sampler* s, const float* x_dev, void* stream);
 int lmc_sampler_get_state(lmc_sampler* s, float* x_dev, void* stream);

@@ -73,7 +73,9 @@ class MYULASampler:
         self.moments_on = bool(moments)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _capi.check(_dev.lib().lmc_myula_create(C.byref(cfg), C.byref(self._h)))
+            _capi.check(getattr(_dev.lib(), self._create_fn)(C.byref(cfg), C.byref(self._h)))
+
+    _create_fn = "lmc_myula_create"
 
     # -- lifetime ------------------------------------------------------------------------
     def close(self):
@@ -413,6 +415,59 @@ def MoreauYosidaUnadjustedLangevin(proxf, proxg, x0, tau=None, gamma=.1, epsg=1.
         torch.cuda.current_stream().synchronize()
         mean, var = mean_var_from_moments(s1, s2, max(cnt, 1))
         return MYULAResult(state, mean, var, cnt, f, g, time.time() - tstart)
+    finally:
+        smp.close()
+
+
+class MYMALASampler(MYULASampler):
+    """Metropolis-adjusted MYULA (MYMALA) for many chains at image scale: the accept / reject of the reference's toy
+    ``ProximalLangevinMonteCarlo.mymala`` (prox_lmc.py:134-158) generalised to ``[C, H, W]`` states, everything on the device.
+    Same constructor as :class:`MYULASampler`; a rejected chain keeps its state (and is counted again by the moments)."""
+
+    _create_fn = "lmc_mymala_create"
+
+    def acceptance(self):
+        """(accepted proposals per chain [C] int64 tensor, log acceptance ratio of the last iteration [C] float64 tensor)."""
+        acc = torch.empty(self.n_chains, dtype=torch.int64, device=self.device)
+        la = torch.empty(self.n_chains, dtype=torch.float64, device=self.device)
+        _capi.check(_dev.lib().lmc_sampler_get_acceptance(self._h, _dev.ptr(acc), _dev.ptr(la), _dev.stream_ptr()))
+        return acc, la
+
+    def acceptance_rate(self):
+        acc, _ = self.acceptance()
+        return acc.double() / max(self.iteration, 1)
+
+
+def MoreauYosidaMetropolisAdjustedLangevin(proxf, proxg, x0, tau=None, gamma=.1, epsg=1., niter=10, seed=0, callback=None, *,
+                                           n_chains=1, dims=None, chain_offset=0, burn_in=0, thin=1, device=None):
+    """MYMALA at image scale for ``n_chains`` chains (the accept / reject of prox_lmc.py:134-158 around the MYULA move of
+    algs.py:569): returns a :class:`MYULAResult` with two extra attributes, ``accepted`` (per-chain counts) and
+    ``acceptance_rate``.  ``callback(state)`` after every iteration if given."""
+    if dims is None:
+        dims = getattr(proxf, "dims", None) or getattr(proxg, "dims", None)
+    if dims is None:
+        raise ValueError("image shape unknown: pass dims=(ny, nx)")
+    smp = MYMALASampler(proxf, proxg, dims, n_chains=int(n_chains), tau=tau, gamma=gamma, epsg=epsg, seed=seed,
+                        chain_offset=chain_offset, moments=True, burn_in=burn_in, thin=thin, device=device)
+    try:
+        smp.set_state(x0)
+        tstart = time.time()
+        if callback is None:
+            smp.step(niter)
+        else:
+            for _ in range(niter):
+                smp.step(1)
+                callback(smp.get_state())
+        s1, s2, cnt = smp.moments()
+        f, g = smp.energies()
+        state = smp.get_state()
+        acc, _ = smp.acceptance()
+        torch.cuda.current_stream().synchronize()
+        mean, var = mean_var_from_moments(s1, s2, max(cnt, 1))
+        res = MYULAResult(state, mean, var, cnt, f, g, time.time() - tstart)
+        res.accepted = acc
+        res.acceptance_rate = acc.double() / max(niter, 1)
+        return res
     finally:
         smp.close()
 

@@ -348,6 +348,12 @@ struct lmc_sampler {
   double* s1 = nullptr;
   double* s2 = nullptr;
   lmc::StepArgs base{};
+  // MYMALA state (kind == 2): proposal mean of the current state, proposal, its mean, energies, decisions
+  float* mx = nullptr; float* xp = nullptr; float* mxp = nullptr;
+  double* mala_d = nullptr;              // [5C]: U(x), f(x'), g(x'), ||x'-m(x)||^2, ||x-m(x')||^2 ; then [C] log alpha
+  int* flag = nullptr;
+  unsigned long long* nacc = nullptr;
+  bool mala_fresh = false;               // mx / U match x[cur]
   std::vector<hipEvent_t> ev;   // pairs (begin, end) around each step-kernel launch of the last step() call
   bool timing = false;
   bool timed = false;
@@ -607,8 +613,12 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
 
 void lmc_sampler_destroy(lmc_sampler* s) {
   if (!s) return;
-  for (float* b : {s->zero_y, s->xhat, s->ydual, s->uw, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra, s->pxbuf})
+  for (float* b : {s->zero_y, s->xhat, s->ydual, s->uw, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra, s->pxbuf,
+                   s->mx, s->xp, s->mxp})
     if (b) (void)hipFree(b);
+  if (s->mala_d) (void)hipFree(s->mala_d);
+  if (s->flag) (void)hipFree(s->flag);
+  if (s->nacc) (void)hipFree(s->nacc);
   if (s->scal) (void)hipFree(s->scal);
   if (s->x[0]) (void)hipFree(s->x[0]);
   if (s->x[1]) (void)hipFree(s->x[1]);
@@ -623,6 +633,7 @@ int lmc_sampler_set_state(lmc_sampler* s, const float* x_dev, void* stream) {
   const size_t nbytes = sizeof(float) * (size_t)s->C * s->prob.H * s->prob.W;
   HIP_TRY(hipMemcpyAsync(s->x[s->cur], x_dev, nbytes, hipMemcpyDeviceToDevice, S(stream)));
   if (s->kind == 1) HIP_TRY(hipMemcpyAsync(s->xhat, x_dev, nbytes, hipMemcpyDeviceToDevice, S(stream)));   // xhat = x (algs.py:426)
+  s->mala_fresh = false;
   return LMC_OK;
 }
 
@@ -634,9 +645,54 @@ int lmc_sampler_get_state(lmc_sampler* s, float* x_dev, void* stream) {
 }
 
 static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, hipStream_t st);
+static int mymala_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, hipStream_t st);
+
+// f(x_c), g(x_c) of `x` ([C][H][W]) with the sampler's problem and scratch buffers
+static int sampler_energies_at(lmc_sampler* s, const float* x, double* f_out_dev, double* g_out_dev, hipStream_t st) {
+  HIP_TRY(lmc::launch_energies(x, s->C, energy_args(s->prob), f_out_dev, g_out_dev, st));
+  if (s->prob.prior_kind == LMC_PRIOR_HAAR_L1 && g_out_dev)
+    HIP_TRY(lmc::launch_haar_value(x, s->C, s->prob.H, s->prob.W, s->prob.prior_sigma, g_out_dev, st));
+  if (s->prob.ncvx_kind == LMC_NCVX_ME_TV && f_out_dev) {
+    HIP_TRY(g_scratch.need_dbl(2 * (size_t)s->C));
+    int rc = me_tv_energy(s->prob, x, s->C, f_out_dev, s->extra, s->tvstate[0], s->tvstate[1], g_scratch.dbl, st);
+    if (rc) return rc;
+  }
+  return LMC_OK;
+}
+
+// out = base update of `x_in` with the sampler's coefficients; noise_scale 0 gives the proposal mean m(x_in)
+static int sampler_update(lmc_sampler* s, const float* x_in, float* x_out, bool with_noise, const float* noise, uint32_t iteration,
+                          hipStream_t st, const char** kname) {
+  lmc::StepArgs A = s->base;
+  A.x_in = x_in;
+  A.x_out = x_out;
+  A.iteration = iteration;
+  A.noise = noise;
+  if (!with_noise) { A.s = 0.f; A.noise_mode = LMC_NOISE_NONE; A.noise = nullptr; }
+  sanitize_pointers(A);
+  if (s->prob.ncvx_kind == LMC_NCVX_ME_TV) {   // inner prox of the Moreau-envelope term, then the fused step
+    int rc = me_tv_prox(s->prob, A.x_in, s->extra, s->C, s->tvstate[0], s->tvstate[1], st);
+    if (rc) return rc;
+    A.extra = s->extra;
+    A.extra_coef = -s->prob.ncvx_lambda / s->prob.ncvx_gamma;
+  }
+  hipError_t e = launch_step(A, st, kname, s->tvstate[0], s->tvstate[1], s->pxbuf);
+  if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no step-kernel variant covers this configuration");
+  HIP_TRY(e);
+  return LMC_OK;
+}
 
 int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, void* stream) {
   if (!s) return fail(LMC_E_INVALID, "NULL sampler");
+  if (s->kind == 2) {
+    if (n_iters < 0) return fail(LMC_E_INVALID, "n_iters < 0");
+    if (s->noise_mode == LMC_NOISE_INJECTED && !noise_dev && n_iters > 0)
+      return fail(LMC_E_INVALID, "noise_mode is INJECTED but noise_dev is NULL");
+    if (s->noise_mode != LMC_NOISE_INJECTED && noise_dev)
+      return fail(LMC_E_INVALID, "noise_dev given but noise_mode is not INJECTED");
+    if (s->iteration + n_iters > 0xFFFFFFFFLL) return fail(LMC_E_STATE, "iteration counter would exceed 32 bits");
+    return mymala_step(s, n_iters, noise_dev, S(stream));
+  }
   if (s->kind == 1) {
     if (n_iters < 0) return fail(LMC_E_INVALID, "n_iters < 0");
     if (s->noise_mode == LMC_NOISE_INJECTED && !noise_dev && n_iters > 0)
@@ -692,6 +748,88 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     ++s->last_launches;
   }
   s->timed = s->timing;
+  return LMC_OK;
+}
+
+// ---- MYMALA: Metropolis-adjusted MYULA at image scale (generalises prox_lmc.py:134-158) -------------------------------
+int lmc_mymala_create(const lmc_myula_config* cfg, lmc_sampler** out) {
+  int rc = lmc_myula_create(cfg, out);
+  if (rc) return rc;
+  lmc_sampler* s = *out;
+  *out = nullptr;
+  if (s->C > 65535) { lmc_sampler_destroy(s); return fail(LMC_E_UNSUPPORTED, "MYMALA: at most 65535 chains per handle"); }
+  s->kind = 2;
+  const size_t nbytes = sizeof(float) * (size_t)s->C * s->prob.H * s->prob.W;
+  hipError_t e = hipMalloc(&s->mx, nbytes);
+  if (e == hipSuccess) e = hipMalloc(&s->xp, nbytes);
+  if (e == hipSuccess) e = hipMalloc(&s->mxp, nbytes);
+  if (e == hipSuccess && s->noise_mode == LMC_NOISE_PHILOX) e = hipMalloc(&s->xi, nbytes);
+  if (e == hipSuccess) e = hipMalloc(&s->mala_d, sizeof(double) * 6 * (size_t)s->C);
+  if (e == hipSuccess) e = hipMalloc(&s->flag, sizeof(int) * (size_t)s->C);
+  if (e == hipSuccess) e = hipMalloc(&s->nacc, sizeof(unsigned long long) * (size_t)s->C);
+  if (e == hipSuccess) e = hipMemset(s->nacc, 0, sizeof(unsigned long long) * (size_t)s->C);
+  if (e == hipSuccess) e = hipMemset(s->mala_d, 0, sizeof(double) * 6 * (size_t)s->C);
+  if (e != hipSuccess) {
+    rc = fail(e == hipErrorOutOfMemory ? LMC_E_NOMEM : LMC_E_HIP, "sampler allocation failed: %s", hipGetErrorString(e));
+    lmc_sampler_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return LMC_OK;
+}
+
+static int mymala_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, hipStream_t st) {
+  const size_t img = (size_t)s->prob.H * s->prob.W, per_iter = (size_t)s->C * img;
+  const int C = s->C;
+  double *U = s->mala_d, *fp = U + C, *gp = U + 2 * C, *d1 = U + 3 * C, *d2 = U + 4 * C, *la = U + 5 * C;
+  float* x = s->x[s->cur];
+  s->timed = false;
+  s->last_launches = 0;
+  const char* kname = nullptr;
+  if (!s->mala_fresh && n_iters > 0) {   // m(x) and U(x) = f(x) + g(x) of the current state (after create / set_state)
+    int rc = sampler_update(s, x, s->mx, false, nullptr, (uint32_t)s->iteration, st, &kname);
+    if (rc) return rc;
+    rc = sampler_energies_at(s, x, fp, gp, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d1, 0, sizeof(double) * C, st));
+    HIP_TRY(lmc::launch_axpy_env(fp, gp, d1, C, -1.f, 1.f, st));        // fp += gp  (f -= (-1) * (g + d1/2) with d1 = 0)
+    HIP_TRY(hipMemcpyAsync(U, fp, sizeof(double) * C, hipMemcpyDeviceToDevice, st));
+    s->mala_fresh = true;
+  }
+  for (int k = 0; k < n_iters; ++k) {
+    const float* xi = noise_dev ? noise_dev + (size_t)k * per_iter : s->xi;
+    if (s->noise_mode == LMC_NOISE_PHILOX)
+      HIP_TRY(lmc::launch_noise(s->xi, C, s->prob.H, s->prob.W, s->base.key0, s->base.key1, (uint32_t)s->iteration, s->base.chain_offset, st));
+    if (s->noise_mode == LMC_NOISE_NONE) {   // deterministic proposal x' = m(x): d1 = 0
+      HIP_TRY(hipMemcpyAsync(s->xp, s->mx, sizeof(float) * per_iter, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemsetAsync(d1, 0, sizeof(double) * C, st));
+    } else {
+      HIP_TRY(lmc::mala_propose(s->mx, xi, s->xp, C, img, s->base.s, d1, st));          // x' and ||x' - m(x)||^2
+    }
+    int rc = sampler_update(s, s->xp, s->mxp, false, nullptr, (uint32_t)s->iteration, st, &kname);   // m(x')
+    if (rc) return rc;
+    rc = sampler_energies_at(s, s->xp, fp, gp, st);                                       // f(x'), g(x')
+    if (rc) return rc;
+    HIP_TRY(lmc::launch_sqdiff(x, s->mxp, C, img, d2, st));                               // ||x - m(x')||^2
+    HIP_TRY(lmc::mala_accept(C, U, fp, gp, d1, d2, s->tau, s->base.key0, s->base.key1, (uint32_t)s->iteration, s->base.chain_offset,
+                             s->flag, s->nacc, la, st));
+    HIP_TRY(lmc::mala_select(s->flag, x, s->mx, s->xp, s->mxp, C, img, st));
+    if (s->moments && s->iteration >= s->burn_in && (s->iteration - s->burn_in) % s->thin == 0) {
+      HIP_TRY(lmc::launch_moments(x, C, s->prob.H, s->prob.W, s->s1, s->s2, st));
+      s->count += (uint64_t)C;
+    }
+    ++s->iteration;
+  }
+  if (kname) s->kernel_name = kname;
+  return LMC_OK;
+}
+
+int lmc_sampler_get_acceptance(lmc_sampler* s, uint64_t* accepted_dev, double* last_log_alpha_dev, void* stream) {
+  if (!s) return fail(LMC_E_INVALID, "NULL sampler");
+  if (s->kind != 2) return fail(LMC_E_STATE, "not a MYMALA sampler");
+  if (accepted_dev) HIP_TRY(hipMemcpyAsync(accepted_dev, s->nacc, sizeof(uint64_t) * (size_t)s->C, hipMemcpyDeviceToDevice, S(stream)));
+  if (last_log_alpha_dev)
+    HIP_TRY(hipMemcpyAsync(last_log_alpha_dev, s->mala_d + 5 * (size_t)s->C, sizeof(double) * (size_t)s->C, hipMemcpyDeviceToDevice, S(stream)));
   return LMC_OK;
 }
 
@@ -876,15 +1014,7 @@ int lmc_sampler_reset_moments(lmc_sampler* s, void* stream) {
 
 int lmc_sampler_energies(lmc_sampler* s, double* f_out_dev, double* g_out_dev, void* stream) {
   if (!s) return fail(LMC_E_INVALID, "NULL sampler");
-  HIP_TRY(lmc::launch_energies(s->x[s->cur], s->C, energy_args(s->prob), f_out_dev, g_out_dev, S(stream)));
-  if (s->prob.prior_kind == LMC_PRIOR_HAAR_L1 && g_out_dev)
-    HIP_TRY(lmc::launch_haar_value(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->prob.prior_sigma, g_out_dev, S(stream)));
-  if (s->prob.ncvx_kind == LMC_NCVX_ME_TV && f_out_dev) {
-    HIP_TRY(g_scratch.need_dbl(2 * (size_t)s->C));
-    int rc = me_tv_energy(s->prob, s->x[s->cur], s->C, f_out_dev, s->extra, s->tvstate[0], s->tvstate[1], g_scratch.dbl, S(stream));
-    if (rc) return rc;
-  }
-  return LMC_OK;
+  return sampler_energies_at(s, s->x[s->cur], f_out_dev, g_out_dev, S(stream));
 }
 
 int lmc_sampler_noise(lmc_sampler* s, int64_t iteration, float* out_dev, void* stream) {

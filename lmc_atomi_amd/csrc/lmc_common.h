@@ -57,6 +57,7 @@ struct StepArgs {
   const float* prox_ext;
 };
 
-constexpr uint32_t kPhiloxStream = 0x4C4D4301u;  // counter word 3
+constexpr uint32_t kPhiloxStream = 0x4C4D4301u;  // counter word 3 (noise field)
+constexpr uint32_t kPhiloxAccept = 0x4C4D4302u;  // counter word 3 (Metropolis uniforms: ctr = (0, iteration, chain, this))
 
 }  // namespace lmc

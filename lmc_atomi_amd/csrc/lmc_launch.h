@@ -77,3 +77,12 @@ hipError_t cg_dir(float* p, const float* r, int64_t C, size_t img, const double*
 hipError_t ulpda_cg_solve(float* u, const float* rhs, float* r, float* p, float* q, float* tmp, double* scal, int64_t C, int H,
                           int W, const BlurTaps& T, float ts, int niter, hipStream_t st);
 }  // namespace lmc
+
+namespace lmc {
+// Metropolis adjustment glue (lmc_mala.hip)
+hipError_t mala_propose(const float* mx, const float* xi, float* xp, int64_t C, size_t img, float s, double* d1, hipStream_t st);
+hipError_t mala_accept(int C, double* U, const double* fp, const double* gp, const double* d1, const double* d2, float tau,
+                       uint32_t key0, uint32_t key1, uint32_t iteration, uint32_t chain_offset, int* flag,
+                       unsigned long long* nacc, double* log_alpha, hipStream_t st);
+hipError_t mala_select(const int* flag, float* x, float* mx, const float* xp, const float* mxp, int64_t C, size_t img, hipStream_t st);
+}  // namespace lmc

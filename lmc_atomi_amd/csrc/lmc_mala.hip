@@ -1,0 +1,82 @@
+// Metropolis adjustment of the MYULA proposal at image scale (MYMALA; generalises prox_lmc.py:134-158 to [C][H][W] states):
+//   x' = m(x) + sqrt(2 tau) xi,   m(x) = (1 - tau/gamma) x - tau grad f(x) + (tau/gamma) prox_{gamma g}(x)   (prox_lmc.py:150)
+//   log alpha = [f(x) + g(x)] - [f(x') + g(x')] - ( ||x - m(x')||^2 - ||x' - m(x)||^2 ) / (4 tau)           (:139-143)
+//   accept if u <= min(1, alpha), u ~ U(0,1)                                                               (:152-154)
+// The two means come from the fused step kernel (s = 0); these kernels are the glue: proposal + its squared norm,
+// the per-chain decision (one thread per chain, Philox uniform), and the conditional per-chain copy.
+#include "lmc_device.h"
+#include "lmc_launch.h"
+
+namespace lmc {
+
+// xp = mx + s * xi ;  d1[c] += sum (s * xi)^2
+__global__ __launch_bounds__(256) void mala_propose_kernel(const float* __restrict__ mx, const float* __restrict__ xi,
+                                                           float* __restrict__ xp, size_t img, float s, double* __restrict__ d1) {
+  __shared__ double scratch[4];
+  const size_t c = blockIdx.y;
+  double acc = 0.0;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.x * blockDim.x) {
+    const float m = mx[c * img + k];
+    const float p = fmaf(s, xi[c * img + k], m);
+    xp[c * img + k] = p;
+    const double d = (double)p - (double)m;
+    acc += d * d;
+  }
+  const double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) unsafeAtomicAdd(&d1[c], t);
+}
+
+hipError_t mala_propose(const float* mx, const float* xi, float* xp, int64_t C, size_t img, float s, double* d1, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(d1, 0, sizeof(double) * C, st);
+  if (e != hipSuccess) return e;
+  int gx = (int)((img + 255) / 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(mala_propose_kernel, dim3(gx, (unsigned)C), dim3(256), 0, st, mx, xi, xp, img, s, d1);
+  return hipGetLastError();
+}
+
+// One thread per chain.  u = u01(first word of Philox(ctr = (0, iteration, global chain, kPhiloxAccept), key = seed)).
+__global__ void mala_accept_kernel(int C, double* __restrict__ U, const double* __restrict__ fp, const double* __restrict__ gp,
+                                   const double* __restrict__ d1, const double* __restrict__ d2, float tau, uint32_t key0,
+                                   uint32_t key1, uint32_t iteration, uint32_t chain_offset, int* __restrict__ flag,
+                                   unsigned long long* __restrict__ nacc, double* __restrict__ log_alpha) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double Up = fp[c] + gp[c];
+  const double la = (U[c] - Up) - (d2[c] - d1[c]) / (4.0 * (double)tau);
+  uint32_t o[4];
+  philox4x32_10(0u, iteration, chain_offset + (uint32_t)c, kPhiloxAccept, key0, key1, o);
+  const double u = (double)u01(o[0]);
+  const int acc = (log(u) <= la) ? 1 : 0;      // NaN (non-finite energies) rejects
+  flag[c] = acc;
+  if (acc) { U[c] = Up; nacc[c] += 1ull; }
+  log_alpha[c] = la;
+}
+
+hipError_t mala_accept(int C, double* U, const double* fp, const double* gp, const double* d1, const double* d2, float tau,
+                       uint32_t key0, uint32_t key1, uint32_t iteration, uint32_t chain_offset, int* flag,
+                       unsigned long long* nacc, double* log_alpha, hipStream_t st) {
+  hipLaunchKernelGGL(mala_accept_kernel, dim3((C + 127) / 128), dim3(128), 0, st, C, U, fp, gp, d1, d2, tau, key0, key1, iteration,
+                     chain_offset, flag, nacc, log_alpha);
+  return hipGetLastError();
+}
+
+// accepted chains: x <- xp, mx <- mxp
+__global__ __launch_bounds__(256) void mala_select_kernel(const int* __restrict__ flag, float* __restrict__ x, float* __restrict__ mx,
+                                                          const float* __restrict__ xp, const float* __restrict__ mxp, size_t img) {
+  const size_t c = blockIdx.y;
+  if (!flag[c]) return;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.x * blockDim.x) {
+    x[c * img + k] = xp[c * img + k];
+    mx[c * img + k] = mxp[c * img + k];
+  }
+}
+
+hipError_t mala_select(const int* flag, float* x, float* mx, const float* xp, const float* mxp, int64_t C, size_t img, hipStream_t st) {
+  int gx = (int)((img + 255) / 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(mala_select_kernel, dim3(gx, (unsigned)C), dim3(256), 0, st, flag, x, mx, xp, mxp, img);
+  return hipGetLastError();
+}
+
+}  // namespace lmc

@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-from . import (Convolve2D, Gradient, L2, L21, TV, L2_ncvx_tv, MoreauYosidaUnadjustedLangevin,
+from . import (Convolve2D, Gradient, L2, L21, TV, L2_ncvx_tv, MoreauYosidaUnadjustedLangevin, MoreauYosidaMetropolisAdjustedLangevin,
                UnadjustedLangevinPrimalDual, signal_noise_ratio, peak_signal_noise_ratio, mean_squared_error)
 
 
@@ -76,9 +76,13 @@ def prox_lmc_deconv(gamma_mc=15., gamma_me=15., sigma=0.75, tau=0.3, N=1000, nit
             res = MoreauYosidaUnadjustedLangevin(f, TV(dims=(ny, nx), sigma=tau, niter=niter_tv), tau=tau_myula,
                                                  gamma=gamma_myula, x0=x0, niter=N, seed=seed, n_chains=n_chains,
                                                  burn_in=burn_in, thin=thin)
+        elif alg == 'MYMALA':                                       # Metropolis-adjusted MYULA (generalises prox_lmc.py:134-158)
+            res = MoreauYosidaMetropolisAdjustedLangevin(f, TV(dims=(ny, nx), sigma=tau, niter=niter_tv), tau=tau_myula,
+                                                         gamma=gamma_myula, x0=x0, niter=N, seed=seed, n_chains=n_chains or 1,
+                                                         burn_in=burn_in, thin=thin)
         else:
-            raise ValueError("alg must be 'ULPDA' or 'MYULA'")
-        mean = res.mean(axis=0) if n_chains is None else res.mean.cpu().numpy().ravel()      # :474
+            raise ValueError("alg must be 'ULPDA', 'MYULA' or 'MYMALA'")
+        mean = res.mean(axis=0) if isinstance(res, np.ndarray) else res.mean.cpu().numpy().ravel()      # :474
         out[name] = {"mean": mean.reshape(ny, nx),
                      "snr": float(signal_noise_ratio(img, mean, dims=(ny, nx))),            # :707-735
                      "psnr": float(peak_signal_noise_ratio(img, mean, dims=(ny, nx))),
@@ -101,7 +105,7 @@ def main(argv=None):
     ap.add_argument("--N", type=int, default=1000)
     ap.add_argument("--niter_l2", type=int, default=50)
     ap.add_argument("--niter_tv", type=int, default=10)
-    ap.add_argument("--alg", default="ULPDA", choices=["ULPDA", "MYULA"])
+    ap.add_argument("--alg", default="ULPDA", choices=["ULPDA", "MYULA", "MYMALA"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--n_chains", type=int, default=None)
     ap.add_argument("--burn_in", type=int, default=0)

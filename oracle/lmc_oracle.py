@@ -891,6 +891,112 @@ def toy_pgld(mus, Sigmas, omegas, lamda, alpha, gamma, K=1000, seed=0):
     return np.array(out)
 
 
+def _mixture_density(theta, mus, Sigmas, omegas):
+    """``prox_lmc.py:42-51``."""
+    d = mus[0].shape[0]
+    den = 0.0
+    for mu, S, om in zip(mus, Sigmas, omegas):
+        S = np.atleast_2d(S)
+        fac = np.einsum('...k,kl,...l->...', theta - mu, np.linalg.inv(S), theta - mu)
+        den = den + om * np.exp(-fac / 2) / np.sqrt((2 * np.pi) ** d * np.abs(np.linalg.det(S)))
+    return den
+
+
+def toy_mymala(mus, Sigmas, omegas, lamda, alpha, mu, gamma, K=1000, seed=0):
+    """MYMALA on the mixture x Laplace target -- ``prox_lmc.py:134-158``: MYULA proposal (:150), acceptance
+    ``min(1, pi(new) q(old|new) / (pi(old) q(new|old)))`` with ``pi = mixture * Laplace`` (:139-143) and
+    ``q(a|b) = N(a; gd_update(b) + prox_update(b), 2 gamma I)`` (:135-136); ``rng.random()`` is drawn after the normal
+    draw of every iteration (:153); only accepted states are appended (:154-155).  Returns ``(states, n_accepted)``."""
+    d = mus[0].shape[0]
+    rng = default_rng(seed)
+    th = rng.standard_normal(d)
+
+    def mean(t):
+        return t - gamma * _mixture_grad_potential(t, mus, Sigmas, omegas) - gamma * (t - _soft(t, lamda * alpha)) / lamda
+
+    def target(t):
+        return _mixture_density(t, mus, Sigmas, omegas) * (alpha / 2) ** d * np.exp(-alpha * np.linalg.norm(t - mu, ord=1, axis=-1))
+
+    def q(a, b):                                       # scipy multivariate_normal(mean, cov=2 gamma).pdf
+        return np.exp(-np.sum((a - mean(b)) ** 2) / (4 * gamma)) / (4 * np.pi * gamma) ** (d / 2)
+
+    out = []
+    for _ in range(K):
+        xi = rng.standard_normal(d)
+        new = mean(th) + np.sqrt(2 * gamma) * xi
+        p = (target(new) / target(th)) * (q(th, new) / q(new, th))
+        if rng.random() <= min(1, p):
+            out.append(new)
+            th = new
+    return np.array(out), len(out)
+
+
+def energies(x, y, h, offset, sigma_f, prior, mask=None):
+    """Per-chain ``f(x_c) = sigma_f/2 ||A x_c - y||^2`` and ``g(x_c)`` of image-shaped states ``x[C, H, W]`` (the two
+    numbers of the energy log, algs.py:578-582), ``prior`` as in :func:`myula_step`."""
+    if mask is not None:
+        r = mask * x - y
+    elif h is not None:
+        r = blur(x, h, offset) - y
+    else:
+        r = x - y
+    f = 0.5 * sigma_f * np.sum(r * r, axis=(-2, -1))
+    kind = prior["kind"]
+    if kind == "tv":
+        g = prior["sigma"] * np.array([tv_value(xc) for xc in x])
+    elif kind == "l1":
+        g = prior["sigma"] * np.sum(np.abs(x), axis=(-2, -1))
+    elif kind == "l2":
+        g = 0.5 * prior["sigma"] * np.sum(x * x, axis=(-2, -1))
+    elif kind == "haar":
+        g = prior["sigma"] * np.array([haar_l1_value(xc, prior.get("levels", 3)) for xc in x])
+    else:
+        g = np.zeros(x.shape[0])
+    return f, g
+
+
+def mymala_batched(x0, y, h, offset, sigma_f, tau, gamma, prior, niter, noise_fn, uniform_fn, mask=None):
+    """MYMALA for ``C`` image-shaped chains: the accept / reject of ``prox_lmc.py:134-158`` with the MYULA proposal of
+    ``algs.py:569`` and target ``exp(-f - g)``, in log form
+    ``log alpha = U(x) - U(x') - (||x - m(x')||^2 - ||x' - m(x)||^2) / (4 tau)``; ``noise_fn(k) -> [C,H,W]``,
+    ``uniform_fn(k) -> [C]``.  A rejected chain keeps its state.  Returns ``(x, accepted[C], log_alpha[niter, C])``."""
+    x = np.array(x0, dtype=np.float64)
+    zero = np.zeros_like(x)
+
+    def mean(v):
+        return myula_step(v, y, h, offset, sigma_f, tau, gamma, prior, zero, mask=mask)
+
+    def U(v):
+        f, g = energies(v, y, h, offset, sigma_f, prior, mask=mask)
+        return f + g
+
+    mx, Ux = mean(x), U(x)
+    acc = np.zeros(x.shape[0], dtype=np.int64)
+    las = []
+    for k in range(niter):
+        xp = mx + np.sqrt(2 * tau) * noise_fn(k)
+        mxp, Uxp = mean(xp), U(xp)
+        d1 = np.sum((xp - mx) ** 2, axis=(-2, -1))
+        d2 = np.sum((x - mxp) ** 2, axis=(-2, -1))
+        la = (Ux - Uxp) - (d2 - d1) / (4 * tau)
+        ok = np.log(uniform_fn(k)) <= la
+        x[ok], mx[ok], Ux[ok] = xp[ok], mxp[ok], Uxp[ok]
+        acc += ok
+        las.append(la)
+    return x, acc, np.array(las)
+
+
+LMC_PHILOX_ACCEPT = 0x4C4D4302
+
+
+def philox_uniforms(seed, iteration, chain_ids):
+    """The Metropolis uniforms of the device: ``u01(first word of Philox(ctr=(0, iteration, chain, LMC_PHILOX_ACCEPT)))``."""
+    chain_ids = np.asarray(chain_ids, dtype=np.uint32).reshape(-1)
+    o0, _, _, _ = philox4x32_10(np.zeros_like(chain_ids), np.uint32(iteration), chain_ids, np.uint32(LMC_PHILOX_ACCEPT),
+                                seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    return _u01(o0).astype(np.float64)
+
+
 # ----------------------------------------------------------------------------------
 # Closed-form prox library (prox.py:9-65), elementwise restatements
 # ----------------------------------------------------------------------------------

