@@ -11,8 +11,9 @@ file:line it follows.  Citations are relative to the reference root.
 Parity status
 -------------
 * Sampler recursions, step formulae, RNG consumption order, output layout
-  (``algs.py:425-449``, ``algs.py:559-570``, ``lmc.py:94-104``, ``prox_lmc.py:99-130``)
-  and the closed-form proxes (``prox.py:9-65``) are PINNED: ``tests/golden/*.npz`` hold
+  (``algs.py:425-449``, ``algs.py:559-570``, ``lmc.py:94-104``, ``prox_lmc.py:99-130``), the Metropolis
+  accept / reject rule of ``prox_lmc.py:134-158`` (``toy_mymala``; its image-scale generalisation ``mymala_batched``
+  uses the same rule in log form) and the closed-form proxes (``prox.py:9-65``) are PINNED: ``tests/golden/*.npz`` hold
   outputs of the reference's own code executed in the build container
   (``tests/golden/make_golden.py``) and ``tests/test_oracle_golden.py`` checks this
   restatement against them bit for bit / to 1e-12.
@@ -24,6 +25,9 @@ Parity status
   tests pin nothing there (``test_pyprox.py`` has no assertions).  These are checked by
   adjoint dot-tests, against ``scipy.signal`` and against an independent converged TV
   solver (``skimage.restoration.denoise_tv_chambolle`` fixture in ``tests/golden``).
+* The Haar-l1 wavelet prior (BASELINE config 5) has no counterpart in the reference; it is build-specified
+  (3-level orthonormal Haar, soft threshold of the detail coefficients) and checked against PyWavelets
+  (``haar_pywt.npz``, made with the conda interpreter).
 
 dtype: every routine computes in the dtype of its input (float64 = the reference's
 dtype; float32 = the device dtype, used for per-step parity with injected noise).
@@ -41,7 +45,7 @@ __all__ = [
     "blur", "blur_adjoint", "grad2d", "div2d", "tv_value", "tv_prox_fgp", "fgp_betas",
     "myula", "ulpda", "myula_batched", "myula_step",
     "philox4x32_10", "philox_normals", "box_muller",
-    "toy_ula", "toy_myula", "toy_pgld",
+    "toy_ula", "toy_myula", "toy_pgld", "toy_mymala", "mymala_batched", "energies", "philox_uniforms",
 ]
 
 # ----------------------------------------------------------------------------------
