@@ -473,9 +473,9 @@ def MoreauYosidaMetropolisAdjustedLangevin(proxf, proxg, x0, tau=None, gamma=.1,
 
 
 def set_step_variant(variant="auto"):
-    """Select the step-kernel variant ('auto' | 'tile' | 'stream' | 'split' | 'point' | 'block' | 'rows'); returns the previous one.
+    """Select the step-kernel variant ('auto' | 'tile' | 'stream' | 'split' | 'point' | 'block' | 'rows' | 'pipe'); returns the previous one.
     All compute the same update -- for A/B tests and profiles."""
-    names = ["auto", "tile", "stream", "split", "point", "block", "rows"]
+    names = ["auto", "tile", "stream", "split", "point", "block", "rows", "pipe"]
     prev = _dev.lib().lmc_set_step_variant(names.index(variant))
     if prev < 0:
         _capi.check(prev)

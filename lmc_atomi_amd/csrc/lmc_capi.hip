@@ -212,7 +212,7 @@ void sanitize_pointers(lmc::StepArgs& A) {
   if (!A.noise) A.noise = A.x_in;
 }
 
-int g_variant = 0;  // 0 auto, 1 tile, 2 stream, 3 split, 4 point, 5 block, 6 rows
+int g_variant = 0;  // 0 auto, 1 tile, 2 stream, 3 split, 4 point, 5 block, 6 rows, 7 pipe
 
 // Picks the step-kernel variant.  auto: the split streaming pipeline (two wave groups, 4 waves/SIMD) when
 // it covers the configuration (W <= 512, separable blur <= 7x7, supported K), else the LDS-tiled kernel.
@@ -239,6 +239,12 @@ hipError_t launch_step(const lmc::StepArgs& A_in, hipStream_t st, const char** n
     return lmc::launch_step_rows(A, st);
   }
   if (v == 6) return hipErrorInvalidConfiguration;
+  // TV K = 10 on a 264..512-wide image with a separable blur: the stage-parallel full-width pipeline
+  if ((v == 0 || v == 7) && lmc::pipe_supported(A)) {
+    if (name) *name = "myula_step_pipe_kernel";
+    return lmc::launch_step_pipe(A, st);
+  }
+  if (v == 7) return hipErrorInvalidConfiguration;
   // auto: split pipeline when it covers the configuration (W <= 512); for wider images the tiled kernels:
   // "point" for closed-form priors with a separable blur, else the general LDS-tiled kernel
   if (v == 0) v = lmc::split_supported(A) ? 3 : (lmc::point_supported(A) ? 4 : (lmc::stream_supported(A) ? 2 : 1));
@@ -1044,8 +1050,8 @@ int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_lau
 const char* lmc_sampler_kernel_name(const lmc_sampler* s) { return s ? s->kernel_name.c_str() : ""; }
 
 int lmc_set_step_variant(int32_t variant) {
-  if (variant < 0 || variant > 6)
-    return fail(LMC_E_INVALID, "variant must be 0 (auto), 1 (tile), 2 (stream), 3 (split), 4 (point), 5 (block) or 6 (rows)");
+  if (variant < 0 || variant > 7)
+    return fail(LMC_E_INVALID, "variant must be 0 (auto), 1 (tile), 2 (stream), 3 (split), 4 (point), 5 (block), 6 (rows) or 7 (pipe)");
   const int prev = g_variant;
   g_variant = variant;
   return prev;

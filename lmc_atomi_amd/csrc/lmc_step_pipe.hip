@@ -1,0 +1,406 @@
+// Fused MYULA update with the isotropic-TV prox (K FGP dual iterations), "pipe" variant:
+//     out = a*x - t*sigma_f H^T(Hx - y) + b*prox_{gamma TV}(x) + s*xi                      (algs.py:569)
+//
+// Same row pipeline as lmc_step_split.hip (stage k runs on row t-E-2k, one barrier per tick) but laid out the other way
+// round: a wavefront owns the FULL WIDTH of the image (lane = PXL consecutive pixels, W <= 64*PXL) and the pipeline STAGES
+// are spread over the wavefronts of the workgroup:
+//   wave 0      "L": HBM load of row t -> x ring (LDS); blur-gradient pipeline on the ring, one row ahead of the output
+//   wave 1..NT  "T": two TV stages each (2j-1, 2j); stage outputs handed to the next wave through LDS (parity double
+//                    buffer, read one tick later -- the latency a stage boundary has anyway)
+//   wave NT+1   "C": final primal step x - gamma div(rr^K, ss^K), combine, HBM store
+//   wave NT+2   "N": Philox normals of the next quad row-group into an LDS slab (read by C four ticks later)
+// Because a wave spans the image width, horizontal neighbours are in the same lane (7 of 8) or one wave-shift DPP move
+// away (2 per stage per PXL pixels): no row-edge ghost exchange, no per-pixel DPP.  One workgroup = one chain.
+#include "lmc_device.h"
+#include "lmc_launch.h"
+
+namespace lmc {
+
+#ifdef LMC_EXP_NOBARRIER   // timing experiment: waves free-run (results are wrong)
+#define PIPE_TICK_SYNC() do {} while (0)
+#else
+#define PIPE_TICK_SYNC() __syncthreads()
+#endif
+
+template <int K>
+struct PipeGeom {
+  static constexpr int D = (2 * K + 2 > 10) ? 2 * K + 2 : 10;   // output row lag: o = t - D
+  static constexpr int E = D - (2 * K + 2);                     // extra lag of the TV pipeline
+  static constexpr int RB = D + 1;                              // x ring rows: t-D .. t
+  static constexpr int NT = K / 2;                              // TV waves (two stages each)
+};
+
+template <int K, int PXL>
+struct PipeLds {
+  static constexpr int BW = 64 * PXL;
+  static constexpr int o_x = 0;                                        // [RB][BW]
+  static constexpr int o_hand = o_x + PipeGeom<K>::RB * BW;            // [NT][2][4][BW]: rr, ss, p, q of the wave's last stage
+  static constexpr int o_g = o_hand + PipeGeom<K>::NT * 2 * 4 * BW;    // [2][BW] gradient of the output row
+  static constexpr int o_slab = o_g + 2 * BW;                          // [2][4][PXL][64] normals of this and the next quad row-group
+  static constexpr int total = o_slab + 2 * 4 * PXL * 64;
+};
+
+// LDS rows are stored so that every 16-byte access of a wave is contiguous: pixel k of lane l at (k>>2)*256 + 4*l + (k&3).
+template <int PXL>
+__device__ __forceinline__ void prow_load(float (&v)[PXL], const float* row, int lane) {
+#pragma unroll
+  for (int g = 0; g < PXL / 4; ++g) {
+    const float4 q = *reinterpret_cast<const float4*>(row + g * 256 + lane * 4);
+    v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+  }
+}
+template <int PXL>
+__device__ __forceinline__ void prow_store(float* row, int lane, const float (&v)[PXL]) {
+#pragma unroll
+  for (int g = 0; g < PXL / 4; ++g)
+    *reinterpret_cast<float4*>(row + g * 256 + lane * 4) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+
+// Packed fp32: gfx950 issues one wave64 VALU instruction per 4 cycles per SIMD, and v_pk_fma/mul/add_f32 process two floats
+// per lane in that slot.  The TV stages therefore work on pixel PAIRS (2i, 2i+1) held in even-aligned register pairs; only
+// the two neighbour-shifted operands of a stage need a v_pk_mov to re-pair, max / rsq stay scalar.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_set(float a) { return v2f{a, a}; }
+
+template <int NP>   // NP = PXL / 2 pairs
+__device__ __forceinline__ void pairs_load(v2f (&v)[NP], const float* row, int lane) {
+#pragma unroll
+  for (int g = 0; g < NP / 2; ++g) {
+    const float4 q = *reinterpret_cast<const float4*>(row + g * 256 + lane * 4);
+    v[2 * g] = v2f{q.x, q.y};
+    v[2 * g + 1] = v2f{q.z, q.w};
+  }
+}
+template <int NP>
+__device__ __forceinline__ void pairs_store(float* row, int lane, const v2f (&v)[NP]) {
+#pragma unroll
+  for (int g = 0; g < NP / 2; ++g)
+    *reinterpret_cast<float4*>(row + g * 256 + lane * 4) = make_float4(v[2 * g].x, v[2 * g].y, v[2 * g + 1].x, v[2 * g + 1].y);
+}
+
+template <int NP>
+struct DualRow { v2f rr[NP], ss[NP], p[NP], q[NP]; };
+
+// One FGP dual iteration on NP pixel pairs per lane.  r1, s1 = (rr, ss)^{k-1} on row a; in0 = (rr, ss, p, q)^{k-1} on row
+// b = a-1; solb = sol^k on row b (in) -> sol^k on row a (out); out = (rr, ss, p, q)^k on row b.
+template <int NP>
+__device__ __forceinline__ void pipe_stage(const v2f (&xa)[NP], const v2f (&r1)[NP], const v2f (&s1)[NP], const DualRow<NP>& in0,
+                                           v2f (&solb)[NP], float gam, float cdown, float cstep, float cr_last, float beta,
+                                           DualRow<NP>& out) {
+  v2f sol[NP];
+  const float ssl0 = dpp_from_left(s1[NP - 1].y, 0.f);
+  const v2f ngam = pk_set(-gam), ncd = pk_set(-cdown), vb = pk_set(beta);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const v2f ssl = v2f{i == 0 ? ssl0 : s1[i - 1].y, s1[i].x};
+    sol[i] = pk_fma(ngam, (r1[i] - in0.rr[i]) + (s1[i] - ssl), xa[i]);
+  }
+  const float solr_last = dpp_from_right(solb[0].x, 0.f);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const v2f solr = v2f{solb[i].y, i == NP - 1 ? solr_last : solb[i + 1].x};
+    const v2f ncr = i == NP - 1 ? v2f{-cstep, -cr_last} : pk_set(-cstep);
+    const v2f r = pk_fma(ncd, sol[i] - solb[i], in0.rr[i]);
+    const v2f s = pk_fma(ncr, solr - solb[i], in0.ss[i]);
+    const v2f n2 = pk_fma(r, r, s * s);
+    const v2f inv = v2f{__builtin_amdgcn_rsqf(fmaxf(n2.x, 1.f)), __builtin_amdgcn_rsqf(fmaxf(n2.y, 1.f))};
+    const v2f pn = r * inv, qn = s * inv;
+    out.rr[i] = pk_fma(vb, pn - in0.p[i], pn);
+    out.ss[i] = pk_fma(vb, qn - in0.q[i], qn);
+    out.p[i] = pn;
+    out.q[i] = qn;
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) solb[i] = sol[i];
+}
+
+template <int PXL>
+__device__ __forceinline__ void gload_row(float (&dst)[PXL], const float* __restrict__ row, int c0, int W, bool ok) {
+#pragma unroll
+  for (int g = 0; g < PXL / 4; ++g) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok && c0 + 4 * g < W) v = *reinterpret_cast<const float4*>(row + c0 + 4 * g);
+    dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
+  }
+}
+
+template <int K, int PXL, int KT>
+__global__ __launch_bounds__(64 * (K / 2 + 3), 1) void myula_step_pipe_kernel(const StepArgs A) {
+  using G = PipeGeom<K>;
+  using L = PipeLds<K, PXL>;
+  constexpr int D = G::D, E = G::E, RB = G::RB, NT = G::NT, BW = L::BW, HW = (KT - 1) / 2;
+  static_assert(K >= 2 && K % 2 == 0, "two stages per TV wave");
+  static_assert(D >= KT + 1, "the blur pipeline reads ring rows at least one tick old");
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int chain = blockIdx.x;
+  const int H = A.H, W = A.W;
+  const int c0 = lane * PXL;
+  const size_t img = (size_t)H * W;
+  const float* __restrict__ xin = A.x_in + (size_t)chain * img;
+  float* __restrict__ xout = A.x_out + (size_t)chain * img;
+
+  for (int e = threadIdx.x; e < L::o_slab; e += blockDim.x) lds[e] = 0.f;   // ring rows < 0, hand-offs of tick -1, g
+  __syncthreads();
+
+  const int T_end = (H + D + 3) & ~3;          // ticks, rounded up to the unroll factor (extra ticks write nothing)
+  float* const xring = lds + L::o_x;
+  auto ring_row = [&](int row) -> float* { return xring + ((unsigned)(row + RB) % (unsigned)RB) * BW; };   // row >= -RB
+
+  if (wave == 0) {
+    // ---------------- L: loader + blur gradient -------------------------------------------------------------
+    const float* __restrict__ uv = A.blur.h;   // centred taps: u[0..KT) then v[0..KT) at h[kMaxBlur..]
+    float xpre[4][PXL], hxw[KT - 1][PXL], hrw[KT - 1][PXL], ypre[PXL];
+#pragma unroll
+    for (int a = 0; a < KT - 1; ++a)
+#pragma unroll
+      for (int k = 0; k < PXL; ++k) { hxw[a][k] = 0.f; hrw[a][k] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gload_row<PXL>(xpre[u], xin + (size_t)min(u, H - 1) * W, c0, W, u < H);
+    {   // observation row of the first residual row
+      const int r = 0 + 1 - D + (KT - 1) - HW;
+      gload_row<PXL>(ypre, A.y + (size_t)min(max(r, 0), H - 1) * W, c0, W, r >= 0 && r < H);
+    }
+    auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
+      constexpr int U = decltype(uu)::value, P = U & 1;
+      {   // row t arrives: publish it in the ring (zeros below the image); fetch row t + 4
+        float xv[PXL];
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) xv[k] = t < H ? xpre[U][k] : 0.f;
+        prow_store<PXL>(ring_row(t), lane, xv);
+        gload_row<PXL>(xpre[U], xin + (size_t)min(t + 4, H - 1) * W, c0, W, t + 4 < H);
+      }
+      const int i = t + 1 - D + (KT - 1);       // blur input row (<= t-1: published in an earlier tick)
+      float hxn[PXL];
+      {
+        float xi[PXL], e[PXL + 2 * HW];
+        prow_load<PXL>(xi, ring_row(i), lane);
+#pragma unroll
+        for (int m = 0; m < HW; ++m) e[m] = dpp_from_left(xi[PXL - HW + m], 0.f);
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) e[HW + k] = xi[k];
+#pragma unroll
+        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_from_right(xi[m], 0.f);
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) {
+          float acc = uv[kMaxBlur] * e[k + 2 * HW];
+#pragma unroll
+          for (int b = 1; b < KT; ++b) acc = fmaf(uv[kMaxBlur + b], e[k + 2 * HW - b], acc);
+          hxn[k] = acc;
+        }
+      }
+      const int r = i - HW;                     // residual row: Hx[r] = sum_a u[a] hx[i - a]
+      float R[PXL];
+      {
+        const bool rowok = r >= 0 && r < H;
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) {
+          float acc = uv[0] * hxn[k];
+#pragma unroll
+          for (int a = 1; a < KT; ++a) acc = fmaf(uv[a], hxw[a - 1][k], acc);
+          R[k] = (rowok && c0 + (k & ~3) < W) ? acc - ypre[k] : 0.f;
+        }
+#pragma unroll
+        for (int a = KT - 2; a >= 1; --a)
+#pragma unroll
+          for (int k = 0; k < PXL; ++k) hxw[a][k] = hxw[a - 1][k];
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) hxw[0][k] = hxn[k];
+        gload_row<PXL>(ypre, A.y + (size_t)min(max(r + 1, 0), H - 1) * W, c0, W, r + 1 >= 0 && r + 1 < H);
+      }
+      {   // horizontal adjoint, then G[r - HW] = sum_a u[a] hR[r - 2HW + a]
+        float e[PXL + 2 * HW], gout[PXL];
+#pragma unroll
+        for (int m = 0; m < HW; ++m) e[m] = dpp_from_left(R[PXL - HW + m], 0.f);
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) e[HW + k] = R[k];
+#pragma unroll
+        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_from_right(R[m], 0.f);
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) {
+          float hrn = uv[kMaxBlur] * e[k];
+#pragma unroll
+          for (int b = 1; b < KT; ++b) hrn = fmaf(uv[kMaxBlur + b], e[k + b], hrn);
+          float acc = uv[KT - 1] * hrn;
+#pragma unroll
+          for (int a = 0; a < KT - 1; ++a) acc = fmaf(uv[a], hrw[KT - 2 - a][k], acc);
+#pragma unroll
+          for (int a = KT - 2; a >= 1; --a) hrw[a][k] = hrw[a - 1][k];
+          hrw[0][k] = hrn;
+          gout[k] = A.sigma_f * acc;
+        }
+        prow_store<PXL>(lds + L::o_g + P * BW, lane, gout);      // row t + 1 - D, read by C next tick
+      }
+      PIPE_TICK_SYNC();
+    };
+    for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
+  } else if (wave <= NT) {
+    // ---------------- T: TV stages k1 = 2*wave - 1 and k2 = 2*wave -----------------------------------------
+    const int k1 = 2 * wave - 1, k2 = 2 * wave;
+    const float gam = A.tv.gamma, cstep = A.tv.c;
+    const float beta1 = A.tv.betas[k1 - 1], beta2 = A.tv.betas[k2 - 1];
+    const float cr_last = (c0 + PXL - 1 == W - 1) ? 0.f : cstep;     // no horizontal difference across column W-1
+    float* const hout = lds + L::o_hand + (wave - 1) * 8 * BW;       // this wave's hand-off [2][4][BW]
+    const float* const hin = hout - 8 * BW;                          // the previous wave's (unused by wave 1)
+    constexpr int NP = PXL / 2;
+    DualRow<NP> inb[2], o1[2];
+    v2f sol1[NP], sol2[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      sol1[k] = sol2[k] = pk_set(0.f);
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        inb[pp].rr[k] = inb[pp].ss[k] = inb[pp].p[k] = inb[pp].q[k] = pk_set(0.f);
+        o1[pp].rr[k] = o1[pp].ss[k] = o1[pp].p[k] = o1[pp].q[k] = pk_set(0.f);
+      }
+    }
+    auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
+      constexpr int P = decltype(uu)::value & 1;
+      const int a2 = t - E - 2 * k2, a1 = t - E - 2 * k1;
+      {   // stage k2 on row a2: inputs are this wave's stage k1, one tick (row a2) and two ticks (row a2-1) old
+        v2f xa2[NP];
+        pairs_load<NP>(xa2, ring_row(a2), lane);
+        const float cdown = ((unsigned)(a2 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
+        DualRow<NP> out;
+        pipe_stage<NP>(xa2, o1[P ^ 1].rr, o1[P ^ 1].ss, o1[P], sol2, gam, cdown, cstep, cr_last, beta2, out);
+        float* hb = hout + P * 4 * BW;
+        pairs_store<NP>(hb, lane, out.rr);
+        pairs_store<NP>(hb + BW, lane, out.ss);
+        pairs_store<NP>(hb + 2 * BW, lane, out.p);
+        pairs_store<NP>(hb + 3 * BW, lane, out.q);
+      }
+      {   // stage k1 on row a1: inputs from the previous wave's hand-off (row a1) and the one read a tick earlier (row a1-1)
+        if (k1 > 1) {
+          const float* hb = hin + (P ^ 1) * 4 * BW;
+          pairs_load<NP>(inb[P].rr, hb, lane);
+          pairs_load<NP>(inb[P].ss, hb + BW, lane);
+          pairs_load<NP>(inb[P].p, hb + 2 * BW, lane);
+          pairs_load<NP>(inb[P].q, hb + 3 * BW, lane);
+        }
+        v2f xa1[NP];
+        pairs_load<NP>(xa1, ring_row(a1), lane);
+        const float cdown = ((unsigned)(a1 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
+        pipe_stage<NP>(xa1, inb[P].rr, inb[P].ss, inb[P ^ 1], sol1, gam, cdown, cstep, cr_last, beta1, o1[P]);
+      }
+      PIPE_TICK_SYNC();
+    };
+    for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
+  } else if (wave == NT + 2) {
+    // ---------------- N: Philox normals, one quad row-group ahead of C -------------------------------------
+    // In the tick of row 4q + NI the normals of pixels NI*PXL/4 .. of quad q + 1 are drawn into the other half of the slab
+    // (spread evenly over the ticks: a burst every 4th tick would stall every wave at the barrier).
+    float* const slab = lds + L::o_slab + lane;        // normal (row q of the quad, pixel k) at slab[(q*PXL + k)*64]
+    auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
+      constexpr int U = decltype(uu)::value;
+      constexpr int NI = ((U - D) % 4 + 4) % 4;        // == o & 3  (t = 4m + U)
+      const int o = t - D;
+      if (A.noise_mode == LMC_NOISE_PHILOX) {
+        const int qn = ((o - NI) >> 2) + 1;             // quad row-group being prepared (o - NI is a multiple of 4)
+        if (qn >= 0 && 4 * qn < H) {
+          float* const sl = slab + (qn & 1) * (4 * PXL * 64);
+#pragma unroll
+          for (int kk = 0; kk < PXL / 4; ++kk) {
+            const int k = NI * (PXL / 4) + kk;
+            float n4[4];
+            quad_normals(A.key0, A.key1, A.iteration, A.chain_offset + (uint32_t)chain, (uint32_t)qn * (uint32_t)W + (uint32_t)(c0 + k), n4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sl[(q * PXL + k) * 64] = n4[q];
+          }
+        }
+      }
+      PIPE_TICK_SYNC();
+    };
+    for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
+  } else {
+    // ---------------- C: final primal step, combine, store --------------------------------------------------
+    const float gam = A.tv.gamma;
+    const float* const hin = lds + L::o_hand + (NT - 1) * 8 * BW;
+    float* const slab = lds + L::o_slab + lane;        // normal (row q of the quad, pixel k) at slab[(q*PXL + k)*64]
+    float crr[2][PXL];
+#pragma unroll
+    for (int k = 0; k < PXL; ++k) crr[0][k] = crr[1][k] = 0.f;
+    auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
+      constexpr int U = decltype(uu)::value, P = U & 1;
+      constexpr int NI = ((U - D) % 4 + 4) % 4;        // == o & 3  (t = 4m + U)
+      const int o = t - D;
+      float css[PXL], xo[PXL], gv[PXL], prox[PXL];
+      prow_load<PXL>(crr[P], hin + (P ^ 1) * 4 * BW, lane);          // rr^K on row o (written last tick)
+      prow_load<PXL>(css, hin + (P ^ 1) * 4 * BW + BW, lane);
+      prow_load<PXL>(xo, ring_row(o), lane);
+      prow_load<PXL>(gv, lds + L::o_g + (P ^ 1) * BW, lane);
+      const float ssl0 = dpp_from_left(css[PXL - 1], 0.f);
+#pragma unroll
+      for (int j = 0; j < PXL; ++j) {
+        const float ssl = j == 0 ? ssl0 : css[j - 1];
+        prox[j] = fmaf(-gam, (crr[P][j] - crr[P ^ 1][j]) + (css[j] - ssl), xo[j]);
+      }
+      if (o >= 0 && o < H) {
+        const float* const slr = slab + ((o >> 2) & 1) * (4 * PXL * 64);
+        const size_t go = (size_t)o * W;
+#pragma unroll
+        for (int g = 0; g < PXL / 4; ++g) {
+          if (c0 + 4 * g < W) {
+            float xi[4] = {0.f, 0.f, 0.f, 0.f}, ex[4] = {0.f, 0.f, 0.f, 0.f};
+            if (A.noise_mode == LMC_NOISE_PHILOX) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) xi[q] = slr[(NI * PXL + 4 * g + q) * 64];
+            } else if (A.noise_mode == LMC_NOISE_INJECTED) {
+              const float4 v = *reinterpret_cast<const float4*>(A.noise + (size_t)chain * img + go + c0 + 4 * g);
+              xi[0] = v.x; xi[1] = v.y; xi[2] = v.z; xi[3] = v.w;
+            }
+            if (A.extra) {
+              const float4 v = *reinterpret_cast<const float4*>(A.extra + (size_t)chain * img + go + c0 + 4 * g);
+              ex[0] = v.x; ex[1] = v.y; ex[2] = v.z; ex[3] = v.w;
+            }
+            float ov[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float x = xo[4 * g + q];
+              float gr = gv[4 * g + q];
+              if (A.extra) gr = fmaf(A.extra_coef, x - ex[q], gr);
+              ov[q] = fmaf(A.a, x, fmaf(-A.t, gr, fmaf(A.b, prox[4 * g + q], A.s * xi[q])));
+            }
+            *reinterpret_cast<float4*>(xout + go + c0 + 4 * g) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+          }
+        }
+      }
+      PIPE_TICK_SYNC();
+    };
+    for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
+  }
+}
+
+int centred_blur_taps(const StepArgs& a, float* uc, float* vc);   // lmc_step_rows.hip
+
+template <int K, int PXL, int KT>
+static constexpr size_t pipe_lds_bytes() { return sizeof(float) * (size_t)PipeLds<K, PXL>::total; }
+
+bool pipe_supported(const StepArgs& a) {
+  if (a.prior_kind != LMC_PRIOR_TV_ISO || a.tv.niter != 10) return false;
+  if (a.data_kind != LMC_DATA_BLUR || a.ncvx_kind != LMC_NCVX_NONE || a.prox_ext) return false;
+  if (a.tv_in || a.tv_out || a.tv_state_only) return false;
+  if (a.W > 512 || a.W <= 256 || (a.W & 7) || a.H < 1) return false;
+  float uc[kMaxBlur], vc[kMaxBlur];
+  return centred_blur_taps(a, uc, vc) == 5;
+}
+
+hipError_t launch_step_pipe(StepArgs a, hipStream_t st) {
+  if (!pipe_supported(a)) return hipErrorInvalidConfiguration;
+  float uc[kMaxBlur] = {0}, vc[kMaxBlur] = {0};
+  const int KT = centred_blur_taps(a, uc, vc);
+  for (int i = 0; i < kMaxBlur; ++i) { a.blur.h[i] = i < KT ? uc[i] : 0.f; a.blur.h[kMaxBlur + i] = i < KT ? vc[i] : 0.f; }
+  auto k = myula_step_pipe_kernel<10, 8, 5>;
+  constexpr size_t lb = pipe_lds_bytes<10, 8, 5>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, dim3(a.C), dim3(64 * (10 / 2 + 3)), lb, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace lmc

@@ -233,7 +233,7 @@ static bool rows_centre(const float* u, int n, int off, int KT, float* out) {
   return true;
 }
 
-static int rows_kt(const StepArgs& a, float* uc, float* vc) {
+int centred_blur_taps(const StepArgs& a, float* uc, float* vc) {
   float u[kMaxBlur] = {0}, v[kMaxBlur] = {0};
   if (a.blur.kh > 7 || a.blur.kw > 7 || !separate_blur_taps(a.blur, u, v)) return 0;
   for (int KT = 5; KT <= 7; KT += 2)
@@ -247,7 +247,7 @@ bool rows_supported(const StepArgs& a) {
   if (a.tv_in || a.tv_out) return false;
   if ((a.W & 3) || a.W > 512 || a.W < 4 || a.H < 1) return false;
   float uc[kMaxBlur], vc[kMaxBlur];
-  const int KT = rows_kt(a, uc, vc);
+  const int KT = centred_blur_taps(a, uc, vc);
   if (KT == 0) return false;
   if (KT == 7 && a.W > 256) return false;      // 7 taps x 8 pixels per lane does not fit the register file at 2 waves / SIMD
   return true;
@@ -256,7 +256,7 @@ bool rows_supported(const StepArgs& a) {
 hipError_t launch_step_rows(StepArgs a, hipStream_t st) {
   if (!rows_supported(a)) return hipErrorInvalidConfiguration;
   float uc[kMaxBlur] = {0}, vc[kMaxBlur] = {0};
-  const int KT = rows_kt(a, uc, vc);
+  const int KT = centred_blur_taps(a, uc, vc);
   for (int i = 0; i < kMaxBlur; ++i) { a.blur.h[i] = i < KT ? uc[i] : 0.f; a.blur.h[kMaxBlur + i] = i < KT ? vc[i] : 0.f; }
   // bands: enough waves to fill 1024 SIMDs a few times over, but >= 16 rows each (a band recomputes KT-1 rows at each end)
   static const int env_band = [] { const char* e = getenv("LMC_ROWS_BAND"); return e ? atoi(e) : 0; }();

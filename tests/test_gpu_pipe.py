@@ -1,0 +1,77 @@
+"""GPU parity of the "pipe" step kernel (TV stages spread over the waves of a workgroup, one wave = full image width)
+against the oracle step and the other step kernels, through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import lmc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+    assert torch.cuda.is_available()
+    import lmc_atomi_amd as la
+    yield la
+    la.set_step_variant("auto")
+
+
+def problem(shape, rng, k=5):
+    img = np.zeros(shape)
+    img[shape[0] // 5:shape[0] // 2 + 1, shape[1] // 4:shape[1] // 2 + 2] = 190.0
+    img += np.linspace(0, 30, shape[1])[None, :]
+    h = np.ones((k, k)) / (k * k)
+    off = (k // 2, k // 2)
+    y = O.blur(img, h, off) + rng.normal(0, 0.75, shape)
+    return img, h, off, y
+
+
+@pytest.mark.parametrize("shape", [(40, 512), (37, 264), (100, 320), (5, 512), (1, 512), (23, 504)])
+def test_pipe_kernel_matches_oracle_step(la, shape):
+    sigma, tau_reg = 0.75, 0.3
+    gamma, tau = sigma ** 2, 0.2 * sigma ** 2
+    rng = np.random.default_rng(21)
+    C, nit = 2, 3
+    img, h, off, y = problem(shape, rng)
+    pf = la.L2(Op=la.Convolve2D(shape, h, offset=off), b=y, sigma=1 / sigma ** 2)
+    pg = la.TV(shape, sigma=tau_reg, niter=10)
+    op = {"kind": "tv", "sigma": tau_reg, "niter": 10, "t": gamma}
+    x0 = img[None] + rng.normal(0, 10, (C,) + shape)
+    noise = rng.standard_normal((nit, C) + shape)
+    la.set_step_variant("pipe")
+    smp = la.MYULASampler(pf, pg, shape, n_chains=C, tau=tau, gamma=gamma, noise="injected")
+    smp.set_state(x0)
+    x = x0.copy()
+    for it in range(nit):
+        smp.step(1, noise=noise[it:it + 1])
+        x = O.myula_step(x, y, h, off, 1 / sigma ** 2, tau, gamma, op, noise[it])
+        got = smp.get_state().cpu().numpy()
+        assert rel(got, x) < 2e-6 * (it + 1), (it, rel(got, x))
+    assert smp.kernel_name == "myula_step_pipe_kernel"
+    smp.close()
+    la.set_step_variant("auto")
+
+
+def test_pipe_kernel_philox_matches_split(la):
+    rng = np.random.default_rng(4)
+    for shape, C in [((128, 512), 5), ((64, 384), 3)]:
+        img, h, off, y = problem(shape, rng)
+        pf = la.L2(Op=la.Convolve2D(shape, h, offset=off), b=y, sigma=1 / 0.75 ** 2)
+        outs = {}
+        for v in ("split", "pipe"):
+            la.set_step_variant(v)
+            smp = la.MYULASampler(pf, la.TV(shape, sigma=0.3, niter=10), shape, n_chains=C, tau=0.1125, gamma=0.5625, seed=3,
+                                  chain_offset=11)
+            smp.set_state(img)
+            smp.step(5)
+            outs[v] = smp.get_state().cpu().numpy()
+            smp.close()
+        assert rel(outs["pipe"], outs["split"]) < 2e-6, (shape, rel(outs["pipe"], outs["split"]))
+    la.set_step_variant("auto")
