@@ -104,7 +104,9 @@ __device__ __forceinline__ void pipe_stage(const v2f (&xa)[NP], const v2f (&r1)[
     const v2f r = pk_fma(ncd, sol[i] - solb[i], in0.rr[i]);
     const v2f s = pk_fma(ncr, solr - solb[i], in0.ss[i]);
     const v2f n2 = pk_fma(r, r, s * s);
-    const v2f inv = v2f{__builtin_amdgcn_rsqf(fmaxf(n2.x, 1.f)), __builtin_amdgcn_rsqf(fmaxf(n2.y, 1.f))};
+    // min(1, rsq(n2)) == rsq(max(n2, 1)) bit for bit (rsq is monotone, rsq(1) = 1); written as a [0,1] clamp it folds into the
+    // output modifier of v_rsq_f32 and the v_max disappears
+    const v2f inv = v2f{__builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(n2.x), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(n2.y), 0.f, 1.f)};
     const v2f pn = r * inv, qn = s * inv;
     out.rr[i] = pk_fma(vb, pn - in0.p[i], pn);
     out.ss[i] = pk_fma(vb, qn - in0.q[i], qn);
@@ -152,6 +154,9 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), 1) void myula_step_pipe_kernel(co
   if (wave == 0) {
     // ---------------- L: loader + blur gradient -------------------------------------------------------------
     const float* __restrict__ uv = A.blur.h;   // centred taps: u[0..KT) then v[0..KT) at h[kMaxBlur..]
+    // the windows of the last KT-1 horizontally filtered rows: with KT = 5 they are rings indexed by (tick & 3), static under the
+    // x4 unroll (row i-a in slot (U-a)&3, the new row replaces the oldest); otherwise they are rotated by moves
+    constexpr bool kRing4 = (KT == 5);
     float xpre[4][PXL], hxw[KT - 1][PXL], hrw[KT - 1][PXL], ypre[PXL];
 #pragma unroll
     for (int a = 0; a < KT - 1; ++a)
@@ -199,15 +204,17 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), 1) void myula_step_pipe_kernel(co
         for (int k = 0; k < PXL; ++k) {
           float acc = uv[0] * hxn[k];
 #pragma unroll
-          for (int a = 1; a < KT; ++a) acc = fmaf(uv[a], hxw[a - 1][k], acc);
+          for (int a = 1; a < KT; ++a) acc = fmaf(uv[a], hxw[kRing4 ? ((U - a) & 3) : a - 1][k], acc);
           R[k] = (rowok && c0 + (k & ~3) < W) ? acc - ypre[k] : 0.f;
         }
+        if constexpr (!kRing4) {
 #pragma unroll
-        for (int a = KT - 2; a >= 1; --a)
+          for (int a = KT - 2; a >= 1; --a)
 #pragma unroll
-          for (int k = 0; k < PXL; ++k) hxw[a][k] = hxw[a - 1][k];
+            for (int k = 0; k < PXL; ++k) hxw[a][k] = hxw[a - 1][k];
+        }
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) hxw[0][k] = hxn[k];
+        for (int k = 0; k < PXL; ++k) hxw[kRing4 ? U : 0][k] = hxn[k];
         gload_row<PXL>(ypre, A.y + (size_t)min(max(r + 1, 0), H - 1) * W, c0, W, r + 1 >= 0 && r + 1 < H);
       }
       {   // horizontal adjoint, then G[r - HW] = sum_a u[a] hR[r - 2HW + a]
@@ -225,10 +232,12 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), 1) void myula_step_pipe_kernel(co
           for (int b = 1; b < KT; ++b) hrn = fmaf(uv[kMaxBlur + b], e[k + b], hrn);
           float acc = uv[KT - 1] * hrn;
 #pragma unroll
-          for (int a = 0; a < KT - 1; ++a) acc = fmaf(uv[a], hrw[KT - 2 - a][k], acc);
+          for (int a = 0; a < KT - 1; ++a) acc = fmaf(uv[a], hrw[kRing4 ? ((U - (KT - 1 - a)) & 3) : KT - 2 - a][k], acc);
+          if constexpr (!kRing4) {
 #pragma unroll
-          for (int a = KT - 2; a >= 1; --a) hrw[a][k] = hrw[a - 1][k];
-          hrw[0][k] = hrn;
+            for (int a = KT - 2; a >= 1; --a) hrw[a][k] = hrw[a - 1][k];
+          }
+          hrw[kRing4 ? U : 0][k] = hrn;
           gout[k] = A.sigma_f * acc;
         }
         prow_store<PXL>(lds + L::o_g + P * BW, lane, gout);      // row t + 1 - D, read by C next tick
@@ -247,9 +256,11 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), 1) void myula_step_pipe_kernel(co
     constexpr int NP = PXL / 2;
     DualRow<NP> inb[2], o1[2];
     v2f sol1[NP], sol2[NP];
+    v2f xk[2][NP];        // x rows read for stage k1 (row a1 = a2 + 2), reused by stage k2 two ticks later: one ring read per tick
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       sol1[k] = sol2[k] = pk_set(0.f);
+      xk[0][k] = xk[1][k] = pk_set(0.f);
 #pragma unroll
       for (int pp = 0; pp < 2; ++pp) {
         inb[pp].rr[k] = inb[pp].ss[k] = inb[pp].p[k] = inb[pp].q[k] = pk_set(0.f);
@@ -260,11 +271,9 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), 1) void myula_step_pipe_kernel(co
       constexpr int P = decltype(uu)::value & 1;
       const int a2 = t - E - 2 * k2, a1 = t - E - 2 * k1;
       {   // stage k2 on row a2: inputs are this wave's stage k1, one tick (row a2) and two ticks (row a2-1) old
-        v2f xa2[NP];
-        pairs_load<NP>(xa2, ring_row(a2), lane);
         const float cdown = ((unsigned)(a2 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
         DualRow<NP> out;
-        pipe_stage<NP>(xa2, o1[P ^ 1].rr, o1[P ^ 1].ss, o1[P], sol2, gam, cdown, cstep, cr_last, beta2, out);
+        pipe_stage<NP>(xk[P], o1[P ^ 1].rr, o1[P ^ 1].ss, o1[P], sol2, gam, cdown, cstep, cr_last, beta2, out);
         float* hb = hout + P * 4 * BW;
         pairs_store<NP>(hb, lane, out.rr);
         pairs_store<NP>(hb + BW, lane, out.ss);
@@ -279,10 +288,9 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), 1) void myula_step_pipe_kernel(co
           pairs_load<NP>(inb[P].p, hb + 2 * BW, lane);
           pairs_load<NP>(inb[P].q, hb + 3 * BW, lane);
         }
-        v2f xa1[NP];
-        pairs_load<NP>(xa1, ring_row(a1), lane);
+        pairs_load<NP>(xk[P], ring_row(a1), lane);      // read two ticks ago as row a1 = this tick's a2: consumed above
         const float cdown = ((unsigned)(a1 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
-        pipe_stage<NP>(xa1, inb[P].rr, inb[P].ss, inb[P ^ 1], sol1, gam, cdown, cstep, cr_last, beta1, o1[P]);
+        pipe_stage<NP>(xk[P], inb[P].rr, inb[P].ss, inb[P ^ 1], sol1, gam, cdown, cstep, cr_last, beta1, o1[P]);
       }
       PIPE_TICK_SYNC();
     };
@@ -383,7 +391,7 @@ bool pipe_supported(const StepArgs& a) {
   if (a.tv_in || a.tv_out || a.tv_state_only) return false;
   if (a.W > 512 || a.W <= 256 || (a.W & 7) || a.H < 1) return false;
   float uc[kMaxBlur], vc[kMaxBlur];
-  return centred_blur_taps(a, uc, vc) == 5;
+  return centred_blur_taps(a, uc, vc) != 0;
 }
 
 hipError_t launch_step_pipe(StepArgs a, hipStream_t st) {
@@ -391,15 +399,19 @@ hipError_t launch_step_pipe(StepArgs a, hipStream_t st) {
   float uc[kMaxBlur] = {0}, vc[kMaxBlur] = {0};
   const int KT = centred_blur_taps(a, uc, vc);
   for (int i = 0; i < kMaxBlur; ++i) { a.blur.h[i] = i < KT ? uc[i] : 0.f; a.blur.h[kMaxBlur + i] = i < KT ? vc[i] : 0.f; }
-  auto k = myula_step_pipe_kernel<10, 8, 5>;
-  constexpr size_t lb = pipe_lds_bytes<10, 8, 5>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k, dim3(a.C), dim3(64 * (10 / 2 + 3)), lb, st, a);
+  auto launch = [&](auto kern, size_t lb, bool& attr_set) -> hipError_t {
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.C), dim3(64 * (10 / 2 + 3)), lb, st, a);
+    return hipSuccess;
+  };
+  static bool set5 = false, set7 = false;
+  hipError_t e = KT == 5 ? launch(myula_step_pipe_kernel<10, 8, 5>, pipe_lds_bytes<10, 8, 5>(), set5)
+                         : launch(myula_step_pipe_kernel<10, 8, 7>, pipe_lds_bytes<10, 8, 7>(), set7);
+  if (e != hipSuccess) return e;
   return hipGetLastError();
 }
 

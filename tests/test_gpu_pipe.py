@@ -33,13 +33,14 @@ def problem(shape, rng, k=5):
     return img, h, off, y
 
 
-@pytest.mark.parametrize("shape", [(40, 512), (37, 264), (100, 320), (5, 512), (1, 512), (23, 504)])
-def test_pipe_kernel_matches_oracle_step(la, shape):
+@pytest.mark.parametrize("shape,k", [((40, 512), 5), ((37, 264), 5), ((100, 320), 5), ((5, 512), 5), ((1, 512), 5), ((23, 504), 5),
+                                     ((40, 512), 7), ((33, 400), 6), ((30, 512), 3)])
+def test_pipe_kernel_matches_oracle_step(la, shape, k):
     sigma, tau_reg = 0.75, 0.3
     gamma, tau = sigma ** 2, 0.2 * sigma ** 2
     rng = np.random.default_rng(21)
     C, nit = 2, 3
-    img, h, off, y = problem(shape, rng)
+    img, h, off, y = problem(shape, rng, k)
     pf = la.L2(Op=la.Convolve2D(shape, h, offset=off), b=y, sigma=1 / sigma ** 2)
     pg = la.TV(shape, sigma=tau_reg, niter=10)
     op = {"kind": "tv", "sigma": tau_reg, "niter": 10, "t": gamma}
@@ -75,3 +76,24 @@ def test_pipe_kernel_philox_matches_split(la):
             smp.close()
         assert rel(outs["pipe"], outs["split"]) < 2e-6, (shape, rel(outs["pipe"], outs["split"]))
     la.set_step_variant("auto")
+
+
+def test_pipe_kernel_with_me_tv_term_matches_tile(la):
+    """The ME-TV term of L2_ncvx_tv (pointwise `extra` input of the combine) through the pipe kernel on a wide image."""
+    rng = np.random.default_rng(9)
+    shape = (48, 512)
+    img, h, off, y = problem(shape, rng)
+    outs = {}
+    for v in ("tile", "auto"):
+        la.set_step_variant(v)
+        pf = la.L2_ncvx_tv(dims=shape, Op=la.Convolve2D(shape, h, offset=off), b=y.ravel(), sigma=1 / 0.75 ** 2, lamda=0.3, gamma=15.0,
+                           isotropic=True, niter=10)
+        smp = la.MYULASampler(pf, la.TV(shape, sigma=0.3, niter=10), shape, n_chains=2, tau=0.1125, gamma=0.5625, seed=1)
+        smp.set_state(img)
+        smp.step(3)
+        outs[v] = smp.get_state().cpu().numpy()
+        if v == "auto":
+            assert smp.kernel_name == "myula_step_pipe_kernel"
+        smp.close()
+    la.set_step_variant("auto")
+    assert rel(outs["auto"], outs["tile"]) < 3e-6, rel(outs["auto"], outs["tile"])
