@@ -151,7 +151,7 @@ __device__ __forceinline__ void split_tick_a(const StepArgs& A, const int t, con
       }
       const float r = fmaf(-cdown, sol - solb, S.rr[k - 1][P]);
       const float s = fmaf(-c.cright, solr - solb, S.ss[k - 1][P]);
-      const float inv = __builtin_amdgcn_rsqf(fmaxf(fmaf(r, r, s * s), 1.f));
+      const float inv = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(fmaf(r, r, s * s)), 0.f, 1.f);   // == rsq(max(., 1)); folds into v_rsq ... clamp
       const float pn = r * inv, qn = s * inv;
       const float beta = A.tv.betas[k - 1];
       const float rn = fmaf(beta, pn - S.p[k - 1][P], pn);
@@ -289,7 +289,7 @@ __device__ __forceinline__ void split_tick_b(const StepArgs& A, const int t, con
         else { rrb = S.rr[k - 1][P]; ssb = S.ss[k - 1][P]; pb = S.p[k - 1][P]; qb = S.q[k - 1][P]; }
         const float r = fmaf(-cdown, sol - solb, rrb);
         const float s = fmaf(-c.cright, solr - solb, ssb);
-        const float inv = __builtin_amdgcn_rsqf(fmaxf(fmaf(r, r, s * s), 1.f));
+        const float inv = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(fmaf(r, r, s * s)), 0.f, 1.f);   // == rsq(max(., 1)); folds into v_rsq ... clamp
         const float pn = r * inv, qn = s * inv;
         const float beta = A.tv.betas[k - 1];
         S.rr[k][P] = fmaf(beta, pn - pb, pn);

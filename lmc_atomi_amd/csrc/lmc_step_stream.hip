@@ -114,7 +114,7 @@ __device__ __forceinline__ void stream_tick(const StepArgs& A, const int t, cons
         const float dx = sol - solb, dy = solr - solb;
         const float r = fmaf(-cdown, dx, S.rr[k - 1][P]);
         const float s = fmaf(-c.cright, dy, S.ss[k - 1][P]);
-        const float inv = __builtin_amdgcn_rsqf(fmaxf(fmaf(r, r, s * s), 1.f));
+        const float inv = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(fmaf(r, r, s * s)), 0.f, 1.f);   // == rsq(max(., 1)); folds into v_rsq ... clamp
         const float pn = r * inv, qn = s * inv;
         const float beta = A.tv.betas[k - 1];
         S.rr[k][P] = fmaf(beta, pn - S.p[k - 1][P], pn);
