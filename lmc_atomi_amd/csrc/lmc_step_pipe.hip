@@ -128,7 +128,7 @@ __device__ __forceinline__ void gload_row(float (&dst)[PXL], const float* __rest
 }
 
 template <int K, int PXL, int KT>
-__global__ __launch_bounds__(64 * (K / 2 + 3), 1) void myula_step_pipe_kernel(const StepArgs A) {
+__global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step_pipe_kernel(const StepArgs A) {
   using G = PipeGeom<K>;
   using L = PipeLds<K, PXL>;
   constexpr int D = G::D, E = G::E, RB = G::RB, NT = G::NT, BW = L::BW, HW = (KT - 1) / 2;
@@ -389,7 +389,8 @@ bool pipe_supported(const StepArgs& a) {
   if (a.prior_kind != LMC_PRIOR_TV_ISO || a.tv.niter != 10) return false;
   if (a.data_kind != LMC_DATA_BLUR || a.ncvx_kind != LMC_NCVX_NONE || a.prox_ext) return false;
   if (a.tv_in || a.tv_out || a.tv_state_only) return false;
-  if (a.W > 512 || a.W <= 256 || (a.W & 7) || a.H < 1) return false;
+  // 8 (4) pixels per lane above (up to) 256 columns; narrower than 129 columns half the lanes idle and the split kernel wins
+  if (a.W > 512 || a.W <= 128 || (a.W & (a.W > 256 ? 7 : 3)) || a.H < 1) return false;
   float uc[kMaxBlur], vc[kMaxBlur];
   return centred_blur_taps(a, uc, vc) != 0;
 }
@@ -408,9 +409,12 @@ hipError_t launch_step_pipe(StepArgs a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(a.C), dim3(64 * (10 / 2 + 3)), lb, st, a);
     return hipSuccess;
   };
-  static bool set5 = false, set7 = false;
-  hipError_t e = KT == 5 ? launch(myula_step_pipe_kernel<10, 8, 5>, pipe_lds_bytes<10, 8, 5>(), set5)
-                         : launch(myula_step_pipe_kernel<10, 8, 7>, pipe_lds_bytes<10, 8, 7>(), set7);
+  static bool set5 = false, set7 = false, set45 = false, set47 = false;
+  hipError_t e;
+  if (a.W > 256) e = KT == 5 ? launch(myula_step_pipe_kernel<10, 8, 5>, pipe_lds_bytes<10, 8, 5>(), set5)
+                             : launch(myula_step_pipe_kernel<10, 8, 7>, pipe_lds_bytes<10, 8, 7>(), set7);
+  else e = KT == 5 ? launch(myula_step_pipe_kernel<10, 4, 5>, pipe_lds_bytes<10, 4, 5>(), set45)
+                   : launch(myula_step_pipe_kernel<10, 4, 7>, pipe_lds_bytes<10, 4, 7>(), set47);
   if (e != hipSuccess) return e;
   return hipGetLastError();
 }

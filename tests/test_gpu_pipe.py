@@ -34,7 +34,8 @@ def problem(shape, rng, k=5):
 
 
 @pytest.mark.parametrize("shape,k", [((40, 512), 5), ((37, 264), 5), ((100, 320), 5), ((5, 512), 5), ((1, 512), 5), ((23, 504), 5),
-                                     ((40, 512), 7), ((33, 400), 6), ((30, 512), 3)])
+                                     ((40, 512), 7), ((33, 400), 6), ((30, 512), 3),
+                                     ((64, 256), 5), ((30, 132), 5), ((9, 200), 3), ((50, 252), 7), ((256, 256), 5)])
 def test_pipe_kernel_matches_oracle_step(la, shape, k):
     sigma, tau_reg = 0.75, 0.3
     gamma, tau = sigma ** 2, 0.2 * sigma ** 2
