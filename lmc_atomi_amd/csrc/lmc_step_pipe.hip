@@ -326,9 +326,9 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
     const float gam = A.tv.gamma;
     const float* const hin = lds + L::o_hand + (NT - 1) * 8 * BW;
     float* const slab = lds + L::o_slab + lane;        // normal (row q of the quad, pixel k) at slab[(q*PXL + k)*64]
-    float crr[2][PXL];
+    float crr[2][PXL], xprev[PXL];
 #pragma unroll
-    for (int k = 0; k < PXL; ++k) crr[0][k] = crr[1][k] = 0.f;
+    for (int k = 0; k < PXL; ++k) crr[0][k] = crr[1][k] = xprev[k] = 0.f;
     auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
       constexpr int U = decltype(uu)::value, P = U & 1;
       constexpr int NI = ((U - D) % 4 + 4) % 4;        // == o & 3  (t = 4m + U)
@@ -343,6 +343,22 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
       for (int j = 0; j < PXL; ++j) {
         const float ssl = j == 0 ? ssl0 : css[j - 1];
         prox[j] = fmaf(-gam, (crr[P][j] - crr[P ^ 1][j]) + (css[j] - ssl), xo[j]);
+      }
+      if (A.ncvx_kind == LMC_NCVX_MC_TV) {   // - lambda * A^T(A x / max(|A x|, gamma))  (algs.py:273-277, 291), added to the gradient
+        // rows o-1 (kept in registers: its ring slot is being overwritten by row t this very tick), o, o+1 (ring)
+        float xp[PXL];
+        prow_load<PXL>(xp, ring_row(o + 1), lane);
+        const float xm_r = dpp_from_right(xprev[0], 0.f), x0_l = dpp_from_left(xo[PXL - 1], 0.f), x0_r = dpp_from_right(xo[0], 0.f),
+                    xp_l = dpp_from_left(xp[PXL - 1], 0.f);
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) {
+          const int col = c0 + j;
+          gv[j] -= A.ncvx_lambda * mc_tv_grad(xprev[j], j == PXL - 1 ? xm_r : xprev[j + 1], j == 0 ? x0_l : xo[j - 1], xo[j],
+                                              j == PXL - 1 ? x0_r : xo[j + 1], j == 0 ? xp_l : xp[j - 1], xp[j], o > 0, o + 1 < H, col > 0,
+                                              col + 1 < W, A.ncvx_gamma);
+        }
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) xprev[j] = xo[j];
       }
       if (o >= 0 && o < H) {
         const float* const slr = slab + ((o >> 2) & 1) * (4 * PXL * 64);
@@ -387,7 +403,7 @@ static constexpr size_t pipe_lds_bytes() { return sizeof(float) * (size_t)PipeLd
 
 bool pipe_supported(const StepArgs& a) {
   if (a.prior_kind != LMC_PRIOR_TV_ISO || a.tv.niter != 10) return false;
-  if (a.data_kind != LMC_DATA_BLUR || a.ncvx_kind != LMC_NCVX_NONE || a.prox_ext) return false;
+  if (a.data_kind != LMC_DATA_BLUR || a.prox_ext) return false;
   if (a.tv_in || a.tv_out || a.tv_state_only) return false;
   // 8 (4) pixels per lane above (up to) 256 columns; narrower than 129 columns half the lanes idle and the split kernel wins
   if (a.W > 512 || a.W <= 128 || (a.W & (a.W > 256 ? 7 : 3)) || a.H < 1) return false;

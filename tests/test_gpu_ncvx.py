@@ -60,7 +60,7 @@ def test_mc_tv_large_image_all_kernels_agree(la):
     y = O.blur(img, h, (2, 2)) + rng.normal(0, 0.75, shape)
     x0 = img[None] + rng.normal(0, 20.0, (2,) + shape)      # differences well above and below gamma = 15
     outs = {}
-    for v in ("tile", "split"):
+    for v in ("tile", "split", "pipe"):
         la.set_step_variant(v)
         mc = la.L2_ncvx_tv(dims=shape, Op=la.Convolve2D(shape, h), Op2=la.Gradient(shape), b=y.ravel(), sigma=1 / 0.5625,
                            lamda=0.3, gamma=15.0, isotropic=True)
@@ -72,6 +72,24 @@ def test_mc_tv_large_image_all_kernels_agree(la):
         smp.close()
     la.set_step_variant("auto")
     assert rel(outs["split"], outs["tile"]) < 2e-6
+    assert rel(outs["pipe"], outs["tile"]) < 2e-6
+    # 4 pixels per lane (W <= 256), image rows not a multiple of anything
+    shape2 = (37, 200)
+    img2 = np.zeros(shape2); img2[8:25, 40:150] = 200.0
+    y2 = O.blur(img2, h, (2, 2)) + rng.normal(0, 0.75, shape2)
+    x02 = img2[None] + rng.normal(0, 20.0, (3,) + shape2)
+    o2 = {}
+    for v in ("tile", "pipe"):
+        la.set_step_variant(v)
+        mc = la.L2_ncvx_tv(dims=shape2, Op=la.Convolve2D(shape2, h), Op2=la.Gradient(shape2), b=y2.ravel(), sigma=1 / 0.5625,
+                           lamda=0.3, gamma=15.0, isotropic=True)
+        smp = la.MYULASampler(mc, la.TV(shape2, sigma=0.3, niter=10), shape2, n_chains=3, tau=0.1125, gamma=0.5625, seed=4)
+        smp.set_state(x02)
+        smp.step(3)
+        o2[v] = smp.get_state().cpu().numpy()
+        smp.close()
+    la.set_step_variant("auto")
+    assert rel(o2["pipe"], o2["tile"]) < 2e-6
     mco = O.L2NcvxTV(shape, Op=O.Convolve2D(shape, h), Op2=O.Gradient(shape), b=y.ravel(), sigma=1 / 0.5625, lamda=0.3, gamma=15.0)
     mc = la.L2_ncvx_tv(dims=shape, Op=la.Convolve2D(shape, h), Op2=la.Gradient(shape), b=y.ravel(), sigma=1 / 0.5625,
                        lamda=0.3, gamma=15.0, isotropic=True)
