@@ -286,14 +286,16 @@ int cg_solve_fused(const Problem& q, float ts, float* u, const float* rhs, float
   A.prior_kind = LMC_PRIOR_NONE;
   A.a = 1.f; A.t = -ts / q.sigma_f; A.b = 0.f; A.s = 0.f;
   A.noise_mode = LMC_NOISE_NONE;
-  auto apply = [&](const float* in, float* out) -> hipError_t { A.x_in = in; A.x_out = out; return launch_step(A, st, nullptr); };
+  const char* kname = nullptr;
+  auto apply = [&](const float* in, float* out) -> hipError_t { A.x_in = in; A.x_out = out; return launch_step(A, st, &kname); };
   HIP_TRY(hipMemsetAsync(scal, 0, sizeof(double) * 3 * C, st));
   HIP_TRY(apply(u, qq));
+  A.dot_out = pq;            // the row-streaming kernel accumulates p.Ap while it writes Ap (one pass less per iteration)
   HIP_TRY(lmc::cg_init(rhs, qq, r, p, C, img, rs, st));
   for (int it = 0; it < niter; ++it) {
     HIP_TRY(hipMemsetAsync(pq, 0, sizeof(double) * 2 * C, st));     // pq and rs_new are adjacent
     HIP_TRY(apply(p, qq));
-    HIP_TRY(lmc::cg_dot(p, qq, C, img, pq, st));
+    if (!kname || std::strcmp(kname, "myula_step_rows_kernel") != 0) HIP_TRY(lmc::cg_dot(p, qq, C, img, pq, st));
     HIP_TRY(lmc::cg_update(u, r, p, qq, C, img, rs, pq, rs_new, st));
     HIP_TRY(lmc::cg_dir(p, r, C, img, rs, rs_new, st));
     HIP_TRY(hipMemcpyAsync(rs, rs_new, sizeof(double) * C, hipMemcpyDeviceToDevice, st));

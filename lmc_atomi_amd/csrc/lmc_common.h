@@ -53,6 +53,8 @@ struct StepArgs {
   // extra gradient term g += extra_coef * (x - extra[c][i][j])   (ME-TV: extra = prox_{gamma TV}(x), algs.py:282)
   const float* extra;
   float extra_coef;
+  // rows kernel only: dot_out[c] += sum_ij x_in[c][i][j] * x_out[c][i][j] (the p.Ap of a CG iteration, fused into the operator apply)
+  double* dot_out;
   // prox computed by a preceding launch (Haar-l1 wavelet prior): px = prox_ext[c][i][j]; the kernel's own prior is NONE
   const float* prox_ext;
 };

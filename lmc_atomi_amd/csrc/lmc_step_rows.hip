@@ -38,8 +38,8 @@ __device__ __forceinline__ void rows_load(float (&dst)[PXL], const float* __rest
   }
 }
 
-template <int PXL, int KT>
-__global__ __launch_bounds__(256, PXL == 8 ? 2 : 3) void myula_step_rows_kernel(const StepArgs P, const int band_rows, const int nbands) {
+template <int PXL, int KT, bool DOT = false>
+__global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step_rows_kernel(const StepArgs P, const int band_rows, const int nbands) {
   using Gm = RowsGeom<PXL, KT>;
   constexpr int HW = Gm::HW, LAG = Gm::LAG, PF = Gm::PF;
   const int lane = threadIdx.x & 63;
@@ -83,6 +83,8 @@ __global__ __launch_bounds__(256, PXL == 8 ? 2 : 3) void myula_step_rows_kernel(
     const int r = i_first - HW;
     rows_load<PXL>(yq[0], P.y + (size_t)max(r, 0) * W, c0, W, r >= 0 && r < H);
   }
+
+  double dacc = 0.0;       // sum x_in * x_out over this wave's band (P.dot_out: the p.Ap of CG)
 
   // One step = input row i = base + J (J = i & 7 is a compile-time constant: every ring slot below is static).
   // No step is conditional, so a ring slot is dead between its last read and the assignment that restarts it.
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256, PXL == 8 ? 2 : 3) void myula_step_rows_kernel(
               else if (P.prior_kind == LMC_PRIOR_L1) px = copysignf(fmaxf(fabsf(x) - P.prior_p0, 0.f), x);
               if (P.prox_ext) px = pe[q];
               ov[q] = fmaf(P.a, x, fmaf(-P.t, gr, fmaf(P.b, px, P.s * xi[q])));
+              if constexpr (DOT) dacc = fma((double)x, (double)ov[q], dacc);
             }
             *reinterpret_cast<float4*>(xout + go + c0 + 4 * g) = make_float4(ov[0], ov[1], ov[2], ov[3]);
           }
@@ -219,6 +222,10 @@ __global__ __launch_bounds__(256, PXL == 8 ? 2 : 3) void myula_step_rows_kernel(
   static_for<8 - LAG, 8>([&](auto jj) { step(jj, r0 - 8); });                    // fill: rows r0-LAG .. r0-1, nothing to emit
   for (int base = r0; base < r1r; base += 8) static_for<0, 8>([&](auto jj) { step(jj, base); });
   static_for<0, LAG>([&](auto jj) { step(jj, r1r); });                          // drain: the last LAG output rows
+  if constexpr (DOT) {
+    const double tot = wave_sum(dacc);
+    if (lane == 0) unsafeAtomicAdd(&P.dot_out[chain], tot);
+  }
 }
 
 bool separate_blur_taps(const BlurTaps& T, float* u, float* v);  // lmc_step_stream.hip
@@ -270,6 +277,15 @@ hipError_t launch_step_rows(StepArgs a, hipStream_t st) {
   const int nbands = (a.H + band - 1) / band;
   const long long waves = (long long)a.C * nbands;
   const int nblk = (int)((waves + 3) / 4);
+  if (a.dot_out) {        // CG operator apply with the p.Ap reduction fused (lmc_capi.hip: cg_solve_fused)
+    if (a.W <= 256) {
+      if (KT == 5) hipLaunchKernelGGL((myula_step_rows_kernel<4, 5, true>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+      else hipLaunchKernelGGL((myula_step_rows_kernel<4, 7, true>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+    } else {
+      hipLaunchKernelGGL((myula_step_rows_kernel<8, 5, true>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+    }
+    return hipGetLastError();
+  }
   if (a.W <= 256) {
     if (KT == 5) hipLaunchKernelGGL((myula_step_rows_kernel<4, 5>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
     else hipLaunchKernelGGL((myula_step_rows_kernel<4, 7>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
