@@ -200,7 +200,7 @@ def main():
                             f"{C} chains/GPU x {world} GPU, Philox noise, x0=0, "
                             + ("no moments" if args.no_moments else f"posterior moments every {args.thin} it"),
                 "image": [H, W], "chains_per_gpu": C, "chains_total": C * world, "tv_iters": args.tv_iters,
-                "sampler": "MYULA (algs.py:477-587)" if args.alg == "myula" else f"ULPDA (algs.py:295-474), {args.cg_iters} CG iterations per implicit step", "parallelism": f"chains sharded x{world}",
+                "sampler": "MYULA (algs.py:477-587)" if args.alg == "myula" else f"ULPDA (algs.py:295-474), implicit step by CG: at most {args.cg_iters} iterations, stops at |r| <= 1e-6 |b| for every chain (the reference solver's rule, algs.py:250)", "parallelism": f"chains sharded x{world}",
                 "iterations_per_s": args.steps / elapsed,
             },
             "roofline": {

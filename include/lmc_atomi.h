@@ -257,6 +257,12 @@ int lmc_sampler_get_dual(lmc_sampler* s, float* y_dev, void* stream);
 /* change (tau, mu) for the following iterations (the reference accepts per-iteration arrays, algs.py:402-408) */
 int lmc_sampler_set_steps(lmc_sampler* s, float tau, float mu);
 
+/* Relative residual |r| <= tol |b| at which the inner conjugate-gradient solver of the implicit data step (lmc_l2_prox, ULPDA)
+ * stops before cg_niter / niter iterations -- the stopping rule of the reference's solver (scipy lsqr's btol, default 1e-6, at
+ * algs.py:250).  The test runs on the device for the whole batch of chains (all must satisfy it); tol = 0 disables it.
+ * Default 1e-6.  Returns the previous value; a negative argument only queries. */
+float lmc_set_cg_tolerance(float tol);
+
 /* Step-kernel variant used by lmc_sampler_step / lmc_fused_eval: 0 = auto (default), 1 = LDS-tiled,
  * 2 = streaming register pipeline (one wave group), 3 = the same pipeline split over two wave groups,
  * 4 = HBM-bound tiled kernel for closed-form priors, 5 = register-block kernel (stencil-free data term, prox local to

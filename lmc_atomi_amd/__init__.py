@@ -8,7 +8,7 @@ from .operators import Convolve2D, Diagonal, Gradient, Identity, LinearOperator
 from .proximal import L1, L2, L21, TV, L2_ncvx_tv, WaveletL1, ProxOperator, fgp_betas
 from .algs import (MYULAResult, MYULASampler, MYMALASampler, MoreauYosidaUnadjustedLangevin, MoreauYosidaMetropolisAdjustedLangevin, ULPDASampler,
                    UnadjustedLangevinPrimalDual, mean_var_from_moments,
-                   set_step_variant)
+                   set_step_variant, set_cg_tolerance)
 
 from . import metrics
 from .metrics import MetricsCallback, mean_squared_error, peak_signal_noise_ratio, signal_noise_ratio
@@ -19,6 +19,6 @@ __all__ = [
     "allreduce_moments", "chain_shard", "posterior_mean_var", "sharded_myula",
     "LMCError", "Convolve2D", "Diagonal", "Gradient", "Identity", "LinearOperator",
     "L1", "L2", "L21", "TV", "L2_ncvx_tv", "WaveletL1", "ProxOperator", "fgp_betas",
-    "MYULASampler", "MYMALASampler", "MoreauYosidaMetropolisAdjustedLangevin", "MYULAResult", "MoreauYosidaUnadjustedLangevin", "ULPDASampler", "UnadjustedLangevinPrimalDual", "mean_var_from_moments", "set_step_variant",
+    "MYULASampler", "MYMALASampler", "MoreauYosidaMetropolisAdjustedLangevin", "MYULAResult", "MoreauYosidaUnadjustedLangevin", "ULPDASampler", "UnadjustedLangevinPrimalDual", "mean_var_from_moments", "set_step_variant", "set_cg_tolerance",
 ]
 __version__ = "0.1.0"

@@ -472,6 +472,12 @@ def MoreauYosidaMetropolisAdjustedLangevin(proxf, proxg, x0, tau=None, gamma=.1,
         smp.close()
 
 
+def set_cg_tolerance(tol=1e-6):
+    """Relative residual at which the inner CG solver of the implicit data step stops early (the reference's solver, scipy
+    lsqr, stops at btol = 1e-6 by default, algs.py:250); 0 = always run ``niter`` iterations.  Returns the previous value."""
+    return float(_dev.lib().lmc_set_cg_tolerance(float(tol)))
+
+
 def set_step_variant(variant="auto"):
     """Select the step-kernel variant ('auto' | 'tile' | 'stream' | 'split' | 'point' | 'block' | 'rows' | 'pipe'); returns the previous one.
     All compute the same update -- for A/B tests and profiles."""

@@ -274,10 +274,16 @@ hipError_t launch_step(const lmc::StepArgs& A_in, hipStream_t st, const char** n
 // Conjugate gradients on (I + ts H^T H) u = rhs for every chain, `niter` iterations from the current u.
 // The operator q = p + ts H^T H p is ONE launch of the fused step kernel (out = 1*p - t*grad f(p) with y = 0 and
 // t = -ts/sigma_f), i.e. the same blur pipeline as the sampler; zero_y is an all-zero [H][W] image.
+float g_cg_tol = 1e-6f;   // relative residual at which the inner solver stops (0: always cg_niter iterations)
+
+// scal: 4C + 1 doubles (rs, pq, rs_new, |rhs|^2 per chain, and the "converged" flag).
 int cg_solve_fused(const Problem& q, float ts, float* u, const float* rhs, float* r, float* p, float* qq, double* scal,
                    int64_t C, int niter, const float* zero_y, hipStream_t st) {
   const size_t img = (size_t)q.H * q.W;
-  double *rs = scal, *pq = scal + C, *rs_new = scal + 2 * C;
+  double *rs = scal, *pq = scal + C, *rs_new = scal + 2 * C, *b2 = scal + 3 * C;
+  int* done = reinterpret_cast<int*>(scal + 4 * C);
+  const bool early = g_cg_tol > 0.f;
+  const double tol2 = (double)g_cg_tol * (double)g_cg_tol;
   lmc::StepArgs A;
   std::memset(&A, 0, sizeof A);
   A.H = q.H; A.W = q.W; A.C = (int)C;
@@ -288,16 +294,22 @@ int cg_solve_fused(const Problem& q, float ts, float* u, const float* rhs, float
   A.noise_mode = LMC_NOISE_NONE;
   const char* kname = nullptr;
   auto apply = [&](const float* in, float* out) -> hipError_t { A.x_in = in; A.x_out = out; return launch_step(A, st, &kname); };
-  HIP_TRY(hipMemsetAsync(scal, 0, sizeof(double) * 3 * C, st));
+  HIP_TRY(hipMemsetAsync(scal, 0, sizeof(double) * (4 * C + 1), st));
   HIP_TRY(apply(u, qq));
   A.dot_out = pq;            // the row-streaming kernel accumulates p.Ap while it writes Ap (one pass less per iteration)
-  HIP_TRY(lmc::cg_init(rhs, qq, r, p, C, img, rs, st));
+  if (early) A.skip_flag = done;
+  HIP_TRY(lmc::cg_init(rhs, qq, r, p, C, img, rs, b2, st));
+  // Stopping rule = the reference's: its solver (scipy lsqr, algs.py:250) ends at |r| <= btol |b| with btol = 1e-6 by default,
+  // or after niter iterations.  Here: when EVERY chain of the batch satisfies it.  The test runs on the device; once the flag is
+  // set the kernels of the remaining iterations return at their first instruction (no host synchronisation anywhere).
+  if (early) HIP_TRY(lmc::cg_check(C, rs, b2, tol2, done, st));
   for (int it = 0; it < niter; ++it) {
     HIP_TRY(hipMemsetAsync(pq, 0, sizeof(double) * 2 * C, st));     // pq and rs_new are adjacent
     HIP_TRY(apply(p, qq));
-    if (!kname || std::strcmp(kname, "myula_step_rows_kernel") != 0) HIP_TRY(lmc::cg_dot(p, qq, C, img, pq, st));
-    HIP_TRY(lmc::cg_update(u, r, p, qq, C, img, rs, pq, rs_new, st));
-    HIP_TRY(lmc::cg_dir(p, r, C, img, rs, rs_new, st));
+    if (!kname || std::strcmp(kname, "myula_step_rows_kernel") != 0) HIP_TRY(lmc::cg_dot(p, qq, C, img, pq, early ? done : nullptr, st));
+    HIP_TRY(lmc::cg_update(u, r, p, qq, C, img, rs, pq, rs_new, early ? done : nullptr, st));
+    if (early) HIP_TRY(lmc::cg_check(C, rs_new, b2, tol2, done, st));
+    HIP_TRY(lmc::cg_dir(p, r, C, img, rs, rs_new, early ? done : nullptr, st));
     HIP_TRY(hipMemcpyAsync(rs, rs_new, sizeof(double) * C, hipMemcpyDeviceToDevice, st));
   }
   return LMC_OK;
@@ -487,7 +499,7 @@ int lmc_energies(const lmc_problem* prob, const float* x_dev, int64_t n_img, dou
 
 size_t lmc_l2_prox_workspace_bytes(int64_t n_img, int32_t H, int32_t W) {
   const size_t n = (size_t)n_img * H * W;
-  return ((5 * n * sizeof(float) + 7) / 8) * 8 + 3 * (size_t)n_img * sizeof(double);
+  return ((5 * n * sizeof(float) + 7) / 8) * 8 + (4 * (size_t)n_img + 1) * sizeof(double);
 }
 
 int lmc_l2_prox(const lmc_problem* prob, const float* x_dev, float* out_dev, int64_t n_img, float tau, int32_t niter,
@@ -944,7 +956,7 @@ int lmc_ulpda_create(const lmc_ulpda_config* cfg, lmc_sampler** out) {
   if (s->noise_mode == LMC_NOISE_PHILOX) alloc(&s->xi, n);
   if (s->prob.data_kind == LMC_DATA_BLUR) {
     alloc(&s->cr, n); alloc(&s->cp, n); alloc(&s->cq, n); alloc(&s->ctmp, n); alloc(&s->htb, img); alloc(&s->zero_y, img);
-    if (e == hipSuccess) e = hipMalloc(&s->scal, sizeof(double) * 3 * s->C);
+    if (e == hipSuccess) e = hipMalloc(&s->scal, sizeof(double) * (4 * (size_t)s->C + 1));
     if (e == hipSuccess) e = lmc::launch_blur(s->prob.y, s->htb, 1, s->prob.H, s->prob.W, s->prob.taps, 1, nullptr);   // H^T b
     if (e == hipSuccess) e = hipDeviceSynchronize();
   }
@@ -1050,6 +1062,12 @@ int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_lau
 }
 
 const char* lmc_sampler_kernel_name(const lmc_sampler* s) { return s ? s->kernel_name.c_str() : ""; }
+
+float lmc_set_cg_tolerance(float tol) {
+  const float prev = g_cg_tol;
+  if (tol >= 0.f) g_cg_tol = tol;
+  return prev;
+}
 
 int lmc_set_step_variant(int32_t variant) {
   if (variant < 0 || variant > 7)

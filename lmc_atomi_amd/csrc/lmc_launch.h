@@ -74,11 +74,12 @@ hipError_t ulpda_pointwise_prox(const float* v, float* u, const float* b, const 
                                 int kind, hipStream_t st);
 hipError_t ulpda_finish(float* x, float* xhat, const float* u, const float* xi, int64_t C, int H, int W, float s, float theta,
                         hipStream_t st);
-hipError_t cg_dot(const float* p, const float* q, int64_t C, size_t img, double* pq, hipStream_t st);
-hipError_t cg_init(const float* rhs, const float* q, float* r, float* p, int64_t C, size_t img, double* rs, hipStream_t st);
+hipError_t cg_dot(const float* p, const float* q, int64_t C, size_t img, double* pq, const int* done, hipStream_t st);
+hipError_t cg_init(const float* rhs, const float* q, float* r, float* p, int64_t C, size_t img, double* rs, double* b2, hipStream_t st);
 hipError_t cg_update(float* u, float* r, const float* p, const float* q, int64_t C, size_t img, const double* rs, const double* pq,
-                     double* rs_new, hipStream_t st);
-hipError_t cg_dir(float* p, const float* r, int64_t C, size_t img, const double* rs, const double* rs_new, hipStream_t st);
+                     double* rs_new, const int* done, hipStream_t st);
+hipError_t cg_dir(float* p, const float* r, int64_t C, size_t img, double* rs, const double* rs_new, const int* done, hipStream_t st);
+hipError_t cg_check(int64_t C, const double* rsv, const double* b2, double tol2, int* done, hipStream_t st);
 hipError_t ulpda_cg_solve(float* u, const float* rhs, float* r, float* p, float* q, float* tmp, double* scal, int64_t C, int H,
                           int W, const BlurTaps& T, float ts, int niter, hipStream_t st);
 }  // namespace lmc

@@ -42,6 +42,9 @@ template <int PXL, int KT, bool DOT = false>
 __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step_rows_kernel(const StepArgs P, const int band_rows, const int nbands) {
   using Gm = RowsGeom<PXL, KT>;
   constexpr int HW = Gm::HW, LAG = Gm::LAG, PF = Gm::PF;
+  if constexpr (DOT) {
+    if (P.skip_flag && *P.skip_flag) return;            // CG operator apply after convergence (lmc_capi.hip: cg_solve_fused)
+  }
   const int lane = threadIdx.x & 63;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gw >= P.C * nbands) return;                       // whole waves leave; nothing below synchronises

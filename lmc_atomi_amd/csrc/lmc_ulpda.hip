@@ -131,25 +131,42 @@ __global__ __launch_bounds__(256) void cg_q_kernel(const float* __restrict__ p, 
 // r = rhs - q ; p = r ; rs = dot(r, r)       (CG start, q = A u0)
 __global__ __launch_bounds__(256) void cg_init_kernel(const float* __restrict__ rhs, const float* __restrict__ q,
                                                       float* __restrict__ r, float* __restrict__ p, size_t img,
-                                                      double* __restrict__ rs) {
+                                                      double* __restrict__ rs, double* __restrict__ b2) {
   __shared__ double scratch[4];
   const size_t c = blockIdx.y;
-  double acc = 0.0;
+  double acc = 0.0, accb = 0.0;
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.x * blockDim.x) {
-    const float rv = rhs[c * img + k] - q[c * img + k];
+    const float bv = rhs[c * img + k];
+    const float rv = bv - q[c * img + k];
     r[c * img + k] = rv;
     p[c * img + k] = rv;
     acc += (double)rv * (double)rv;
+    accb += (double)bv * (double)bv;
   }
   const double t = block_sum(acc, scratch);
-  if (threadIdx.x == 0) unsafeAtomicAdd(&rs[c], t);
+  __syncthreads();
+  const double tb = block_sum(accb, scratch);
+  if (threadIdx.x == 0) { unsafeAtomicAdd(&rs[c], t); if (b2) unsafeAtomicAdd(&b2[c], tb); }
+}
+
+// done[0] = 1 when every chain satisfies |r|^2 <= tol^2 |b|^2 (the stopping rule of the reference's solver: scipy lsqr's
+// btol, algs.py:250 with the default 1e-6).  Once set, the kernels of the remaining iterations return at once.
+__global__ __launch_bounds__(256) void cg_check_kernel(int64_t C, const double* __restrict__ rsv, const double* __restrict__ b2,
+                                                       double tol2, int* __restrict__ done) {
+  if (*done) return;
+  int ok = 1;
+  for (int64_t c = threadIdx.x; c < C; c += blockDim.x) ok &= (rsv[c] <= tol2 * b2[c]) ? 1 : 0;
+  ok = __syncthreads_and(ok);
+  if (threadIdx.x == 0 && ok) *done = 1;
 }
 
 // alpha = rs/pq ; u += alpha p ; r -= alpha q ; rs_new = dot(r, r)
 __global__ __launch_bounds__(256) void cg_update_kernel(float* __restrict__ u, float* __restrict__ r, const float* __restrict__ p,
                                                         const float* __restrict__ q, size_t img, const double* __restrict__ rs,
-                                                        const double* __restrict__ pq, double* __restrict__ rs_new) {
+                                                        const double* __restrict__ pq, double* __restrict__ rs_new,
+                                                        const int* __restrict__ done) {
   __shared__ double scratch[4];
+  if (done && *done) return;
   const size_t c = blockIdx.y;
   const double den = pq[c];
   const float alpha = (rs[c] > 0.0 && den != 0.0) ? (float)(rs[c] / den) : 0.f;   // rs == 0: converged, freeze
@@ -166,7 +183,9 @@ __global__ __launch_bounds__(256) void cg_update_kernel(float* __restrict__ u, f
 
 // p = r + (rs_new/rs) p
 __global__ __launch_bounds__(256) void cg_dir_kernel(float* __restrict__ p, const float* __restrict__ r, size_t img,
-                                                     const double* __restrict__ rs, const double* __restrict__ rs_new) {
+                                                     double* __restrict__ rs, const double* __restrict__ rs_new,
+                                                     const int* __restrict__ done) {
+  if (done && *done) return;
   const size_t c = blockIdx.y;
   const float beta = rs[c] > 0.0 ? (float)(rs_new[c] / rs[c]) : 0.f;
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.x * blockDim.x)
@@ -201,8 +220,9 @@ __global__ __launch_bounds__(256) void ulpda_finish_kernel(float* __restrict__ x
 
 // pq[c] = dot(p_c, q_c)
 __global__ __launch_bounds__(256) void cg_dot_kernel(const float* __restrict__ p, const float* __restrict__ q, size_t img,
-                                                     double* __restrict__ pq) {
+                                                     double* __restrict__ pq, const int* __restrict__ done) {
   __shared__ double scratch[4];
+  if (done && *done) return;
   const size_t c = blockIdx.y;
   double acc = 0.0;
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.x * blockDim.x)
@@ -217,21 +237,25 @@ static inline dim3 cg_grid(size_t img, int64_t C) {
   return dim3(gx, (unsigned)C);
 }
 
-hipError_t cg_dot(const float* p, const float* q, int64_t C, size_t img, double* pq, hipStream_t st) {
-  hipLaunchKernelGGL(cg_dot_kernel, cg_grid(img, C), dim3(256), 0, st, p, q, img, pq);
+hipError_t cg_dot(const float* p, const float* q, int64_t C, size_t img, double* pq, const int* done, hipStream_t st) {
+  hipLaunchKernelGGL(cg_dot_kernel, cg_grid(img, C), dim3(256), 0, st, p, q, img, pq, done);
   return hipGetLastError();
 }
-hipError_t cg_init(const float* rhs, const float* q, float* r, float* p, int64_t C, size_t img, double* rs, hipStream_t st) {
-  hipLaunchKernelGGL(cg_init_kernel, cg_grid(img, C), dim3(256), 0, st, rhs, q, r, p, img, rs);
+hipError_t cg_init(const float* rhs, const float* q, float* r, float* p, int64_t C, size_t img, double* rs, double* b2, hipStream_t st) {
+  hipLaunchKernelGGL(cg_init_kernel, cg_grid(img, C), dim3(256), 0, st, rhs, q, r, p, img, rs, b2);
   return hipGetLastError();
 }
 hipError_t cg_update(float* u, float* r, const float* p, const float* q, int64_t C, size_t img, const double* rs, const double* pq,
-                     double* rs_new, hipStream_t st) {
-  hipLaunchKernelGGL(cg_update_kernel, cg_grid(img, C), dim3(256), 0, st, u, r, p, q, img, rs, pq, rs_new);
+                     double* rs_new, const int* done, hipStream_t st) {
+  hipLaunchKernelGGL(cg_update_kernel, cg_grid(img, C), dim3(256), 0, st, u, r, p, q, img, rs, pq, rs_new, done);
   return hipGetLastError();
 }
-hipError_t cg_dir(float* p, const float* r, int64_t C, size_t img, const double* rs, const double* rs_new, hipStream_t st) {
-  hipLaunchKernelGGL(cg_dir_kernel, cg_grid(img, C), dim3(256), 0, st, p, r, img, rs, rs_new);
+hipError_t cg_dir(float* p, const float* r, int64_t C, size_t img, double* rs, const double* rs_new, const int* done, hipStream_t st) {
+  hipLaunchKernelGGL(cg_dir_kernel, cg_grid(img, C), dim3(256), 0, st, p, r, img, rs, rs_new, done);
+  return hipGetLastError();
+}
+hipError_t cg_check(int64_t C, const double* rsv, const double* b2, double tol2, int* done, hipStream_t st) {
+  hipLaunchKernelGGL(cg_check_kernel, dim3(1), dim3(256), 0, st, C, rsv, b2, tol2, done);
   return hipGetLastError();
 }
 
@@ -280,15 +304,15 @@ hipError_t ulpda_cg_solve(float* u, const float* rhs, float* r, float* p, float*
   if ((e = launch_blur(u, tmp, C, H, W, T, 0, st)) != hipSuccess) return e;
   if ((e = launch_blur(tmp, q, C, H, W, T, 1, st)) != hipSuccess) return e;
   hipLaunchKernelGGL(cg_q_kernel, grid, block, 0, st, u, q, img, ts, pq);
-  hipLaunchKernelGGL(cg_init_kernel, grid, block, 0, st, rhs, q, r, p, img, rs);
+  hipLaunchKernelGGL(cg_init_kernel, grid, block, 0, st, rhs, q, r, p, img, rs, (double*)nullptr);
   for (int it = 0; it < niter; ++it) {
     if ((e = hipMemsetAsync(pq, 0, sizeof(double) * C, st)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(rs_new, 0, sizeof(double) * C, st)) != hipSuccess) return e;
     if ((e = launch_blur(p, tmp, C, H, W, T, 0, st)) != hipSuccess) return e;
     if ((e = launch_blur(tmp, q, C, H, W, T, 1, st)) != hipSuccess) return e;
     hipLaunchKernelGGL(cg_q_kernel, grid, block, 0, st, p, q, img, ts, pq);
-    hipLaunchKernelGGL(cg_update_kernel, grid, block, 0, st, u, r, p, q, img, rs, pq, rs_new);
-    hipLaunchKernelGGL(cg_dir_kernel, grid, block, 0, st, p, r, img, rs, rs_new);
+    hipLaunchKernelGGL(cg_update_kernel, grid, block, 0, st, u, r, p, q, img, rs, pq, rs_new, (const int*)nullptr);
+    hipLaunchKernelGGL(cg_dir_kernel, grid, block, 0, st, p, r, img, rs, rs_new, (const int*)nullptr);
     if ((e = hipMemcpyAsync(rs, rs_new, sizeof(double) * C, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
   }
   return hipGetLastError();

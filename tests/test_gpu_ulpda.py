@@ -149,3 +149,34 @@ def test_ulpda_errors(la):
     from lmc_atomi_amd import _capi, _dev
     with pytest.raises(la.LMCError):
         _capi.check(_dev.lib().lmc_sampler_set_steps(smp._h, 0.1, 0.1))   # not a ULPDA handle
+
+
+def test_cg_early_exit_matches_fixed_iterations(la):
+    """The inner solver stops when every chain reaches |r| <= 1e-6 |b| (the reference's lsqr btol, algs.py:250): same solution
+    as the fixed 50 iterations to fp32 accuracy, for the operator-level prox and for ULPDA trajectories; tol = 0 restores the
+    fixed count."""
+    rng = np.random.default_rng(12)
+    shape = (40, 64)
+    img = np.zeros(shape); img[8:30, 10:50] = 120.0
+    h = np.ones((5, 5)) / 25
+    y = O.blur(img, h, (2, 2)) + rng.normal(0, 0.75, shape)
+    v = img[None] + rng.normal(0, 5, (3,) + shape)
+    outs = {}
+    prev = la.set_cg_tolerance(1e-6)
+    assert abs(prev - 1e-6) < 1e-12
+    for tol in (0.0, 1e-6):
+        la.set_cg_tolerance(tol)
+        l2 = la.L2(Op=la.Convolve2D(shape, h, offset=(2, 2)), b=y.ravel(), sigma=1 / 0.75 ** 2, niter=50, warm=False)
+        outs[tol] = np.stack([l2.prox(v[i].ravel().copy(), 0.53) for i in range(3)])
+        smp = la.ULPDASampler(la.L2(Op=la.Convolve2D(shape, h, offset=(2, 2)), b=y.ravel(), sigma=1 / 0.75 ** 2, niter=50, warm=True),
+                              la.L21(ndim=2, sigma=0.3), la.Gradient(shape), shape, n_chains=3, tau=0.95 * 0.5625, mu=1.0, theta=1.0,
+                              gfirst=False, seed=5)
+        smp.set_state(v)
+        smp.step(4)
+        outs[("u", tol)] = smp.get_state().cpu().numpy()
+        smp.close()
+    la.set_cg_tolerance(1e-6)
+    ref = O.L2(Op=O.Convolve2D(shape, h, offset=(2, 2)), b=y.ravel(), sigma=1 / 0.75 ** 2, niter=50, warm=False)
+    want = np.stack([ref.prox(v[i].ravel().copy(), 0.53) for i in range(3)])
+    assert rel(outs[0.0], want) < 2e-6 and rel(outs[1e-6], want) < 5e-6
+    assert rel(outs[("u", 1e-6)], outs[("u", 0.0)]) < 2e-5
