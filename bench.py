@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--tv-iters", type=int, default=10)
     ap.add_argument("--prior", default="tv", choices=["tv", "l2", "l1", "haar"])
     ap.add_argument("--thin", type=int, default=1, help="accumulate posterior moments every thin-th iteration")
-    ap.add_argument("--alg", default="myula", choices=["myula", "ulpda"], help="sampler: MYULA (headline) or ULPDA (algs.py:295-474)")
+    ap.add_argument("--alg", default="myula", choices=["myula", "ulpda", "mymala"], help="sampler: MYULA (headline) or ULPDA (algs.py:295-474)")
     ap.add_argument("--cg-iters", type=int, default=50, help="ULPDA: inner CG iterations of the implicit data step")
     ap.add_argument("--no-moments", action="store_true")
     ap.add_argument("--data", default="blur", choices=["blur", "identity", "mask"], help="data term (experiments)")
@@ -132,8 +132,9 @@ def main():
                               mu=1.0, theta=1.0, gfirst=False, seed=0, chain_offset=rank * C, moments=not args.no_moments,
                               burn_in=0, thin=args.thin, noise=args.noise)
     else:
-        smp = la.MYULASampler(pf, pg, (H, W), n_chains=C, tau=tau, gamma=gamma, seed=0, chain_offset=rank * C,
-                              moments=not args.no_moments, burn_in=0, thin=args.thin, noise=args.noise)
+        cls = la.MYMALASampler if args.alg == "mymala" else la.MYULASampler
+        smp = cls(pf, pg, (H, W), n_chains=C, tau=tau, gamma=gamma, seed=0, chain_offset=rank * C,
+                  moments=not args.no_moments, burn_in=0, thin=args.thin, noise=args.noise)
     smp.set_state(np.zeros((H, W), dtype=np.float32))        # x0 = 0 (prox_lmc_deconv.py:135)
 
     def sync_all():
@@ -200,7 +201,7 @@ def main():
                             f"{C} chains/GPU x {world} GPU, Philox noise, x0=0, "
                             + ("no moments" if args.no_moments else f"posterior moments every {args.thin} it"),
                 "image": [H, W], "chains_per_gpu": C, "chains_total": C * world, "tv_iters": args.tv_iters,
-                "sampler": "MYULA (algs.py:477-587)" if args.alg == "myula" else f"ULPDA (algs.py:295-474), implicit step by CG: at most {args.cg_iters} iterations, stops at |r| <= 1e-6 |b| for every chain (the reference solver's rule, algs.py:250)", "parallelism": f"chains sharded x{world}",
+                "sampler": "MYULA (algs.py:477-587)" if args.alg == "myula" else "MYMALA (Metropolis-adjusted MYULA, generalises prox_lmc.py:134-158)" if args.alg == "mymala" else f"ULPDA (algs.py:295-474), implicit step by CG: at most {args.cg_iters} iterations, stops at |r| <= 1e-6 |b| for every chain (the reference solver's rule, algs.py:250)", "parallelism": f"chains sharded x{world}",
                 "iterations_per_s": args.steps / elapsed,
             },
             "roofline": {

@@ -682,8 +682,19 @@ static int sampler_energies_at(lmc_sampler* s, const float* x, double* f_out_dev
 
 // out = base update of `x_in` with the sampler's coefficients; noise_scale 0 gives the proposal mean m(x_in)
 static int sampler_update(lmc_sampler* s, const float* x_in, float* x_out, bool with_noise, const float* noise, uint32_t iteration,
-                          hipStream_t st, const char** kname) {
+                          hipStream_t st, const char** kname, double* f_out = nullptr, double* g_out = nullptr, bool* fused = nullptr) {
   lmc::StepArgs A = s->base;
+  if (fused) *fused = false;
+  if (f_out && g_out && (g_variant == 0 || g_variant == 7) && s->prob.ncvx_kind == LMC_NCVX_NONE && s->prob.prior_kind == LMC_PRIOR_TV_ISO) {
+    lmc::StepArgs probe = A;
+    probe.x_in = x_in;
+    if (lmc::pipe_supported(probe)) {   // the pipe kernel returns f(x_in), g(x_in) as by-products
+      HIP_TRY(hipMemsetAsync(f_out, 0, sizeof(double) * s->C, st));
+      HIP_TRY(hipMemsetAsync(g_out, 0, sizeof(double) * s->C, st));
+      A.f_out = f_out; A.g_out = g_out; A.g_scale = s->prob.prior_sigma;
+      if (fused) *fused = true;
+    }
+  }
   A.x_in = x_in;
   A.x_out = x_out;
   A.iteration = iteration;
@@ -807,9 +818,10 @@ static int mymala_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, 
   s->last_launches = 0;
   const char* kname = nullptr;
   if (!s->mala_fresh && n_iters > 0) {   // m(x) and U(x) = f(x) + g(x) of the current state (after create / set_state)
-    int rc = sampler_update(s, x, s->mx, false, nullptr, (uint32_t)s->iteration, st, &kname);
+    bool fused = false;
+    int rc = sampler_update(s, x, s->mx, false, nullptr, (uint32_t)s->iteration, st, &kname, fp, gp, &fused);
     if (rc) return rc;
-    rc = sampler_energies_at(s, x, fp, gp, st);
+    if (!fused) rc = sampler_energies_at(s, x, fp, gp, st);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(d1, 0, sizeof(double) * C, st));
     HIP_TRY(lmc::launch_axpy_env(fp, gp, d1, C, -1.f, 1.f, st));        // fp += gp  (f -= (-1) * (g + d1/2) with d1 = 0)
@@ -826,9 +838,10 @@ static int mymala_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, 
     } else {
       HIP_TRY(lmc::mala_propose(s->mx, xi, s->xp, C, img, s->base.s, d1, st));          // x' and ||x' - m(x)||^2
     }
-    int rc = sampler_update(s, s->xp, s->mxp, false, nullptr, (uint32_t)s->iteration, st, &kname);   // m(x')
+    bool fused = false;
+    int rc = sampler_update(s, s->xp, s->mxp, false, nullptr, (uint32_t)s->iteration, st, &kname, fp, gp, &fused);   // m(x') [+ f, g]
     if (rc) return rc;
-    rc = sampler_energies_at(s, s->xp, fp, gp, st);                                       // f(x'), g(x')
+    if (!fused) rc = sampler_energies_at(s, s->xp, fp, gp, st);                           // f(x'), g(x')
     if (rc) return rc;
     HIP_TRY(lmc::launch_sqdiff(x, s->mxp, C, img, d2, st));                               // ||x - m(x')||^2
     HIP_TRY(lmc::mala_accept(C, U, fp, gp, d1, d2, s->tau, s->base.key0, s->base.key1, (uint32_t)s->iteration, s->base.chain_offset,

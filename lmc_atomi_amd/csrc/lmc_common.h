@@ -55,7 +55,12 @@ struct StepArgs {
   float extra_coef;
   // rows kernel only: dot_out[c] += sum_ij x_in[c][i][j] * x_out[c][i][j] (the p.Ap of a CG iteration, fused into the operator apply)
   double* dot_out;
-  const int* skip_flag;      // rows kernel only: the launch returns at once when *skip_flag != 0 (inner solver already converged)
+  const int* skip_flag;
+  // pipe kernel only: energies of x_in as by-products of the update (MYMALA): f_out[c] += sigma_f/2 ||H x - y||^2 (the residual rows
+  // of the blur pipeline), g_out[c] += g_scale * TV_iso(x) (from the ring rows of the combine wave)
+  double* f_out;
+  double* g_out;
+  float g_scale;      // rows kernel only: the launch returns at once when *skip_flag != 0 (inner solver already converged)
   // prox computed by a preceding launch (Haar-l1 wavelet prior): px = prox_ext[c][i][j]; the kernel's own prior is NONE
   const float* prox_ext;
 };

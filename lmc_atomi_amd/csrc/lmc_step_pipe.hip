@@ -168,6 +168,7 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
       const int r = 0 + 1 - D + (KT - 1) - HW;
       gload_row<PXL>(ypre, A.y + (size_t)min(max(r, 0), H - 1) * W, c0, W, r >= 0 && r < H);
     }
+    double facc = 0.0;        // sum of squared residuals (A.f_out)
     auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
       constexpr int U = decltype(uu)::value, P = U & 1;
       {   // row t arrives: publish it in the ring (zeros below the image); fetch row t + 4
@@ -207,6 +208,10 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
           for (int a = 1; a < KT; ++a) acc = fmaf(uv[a], hxw[kRing4 ? ((U - a) & 3) : a - 1][k], acc);
           R[k] = (rowok && c0 + (k & ~3) < W) ? acc - ypre[k] : 0.f;
         }
+        if (A.f_out) {
+#pragma unroll
+          for (int k = 0; k < PXL; ++k) facc = fma((double)R[k], (double)R[k], facc);
+        }
         if constexpr (!kRing4) {
 #pragma unroll
           for (int a = KT - 2; a >= 1; --a)
@@ -245,6 +250,10 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
       PIPE_TICK_SYNC();
     };
     for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
+    if (A.f_out) {
+      const double tot = wave_sum(facc);
+      if (lane == 0) unsafeAtomicAdd(&A.f_out[chain], 0.5 * (double)A.sigma_f * tot);
+    }
   } else if (wave <= NT) {
     // ---------------- T: TV stages k1 = 2*wave - 1 and k2 = 2*wave -----------------------------------------
     const int k1 = 2 * wave - 1, k2 = 2 * wave;
@@ -326,6 +335,7 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
     const float gam = A.tv.gamma;
     const float* const hin = lds + L::o_hand + (NT - 1) * 8 * BW;
     float* const slab = lds + L::o_slab + lane;        // normal (row q of the quad, pixel k) at slab[(q*PXL + k)*64]
+    double gacc = 0.0;        // sum |grad x_in| (A.g_out)
     float crr[2][PXL], xprev[PXL];
 #pragma unroll
     for (int k = 0; k < PXL; ++k) crr[0][k] = crr[1][k] = xprev[k] = 0.f;
@@ -360,6 +370,18 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
 #pragma unroll
         for (int j = 0; j < PXL; ++j) xprev[j] = xo[j];
       }
+      if (A.g_out && o >= 0 && o < H) {   // isotropic TV of the input image, row o: forward differences, zero across the last row / column
+        float xq[PXL];
+        prow_load<PXL>(xq, ring_row(o + 1), lane);
+        const float xr_last = dpp_from_right(xo[0], 0.f);
+        const bool down = o + 1 < H;
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) {
+          const float dx = down ? xq[j] - xo[j] : 0.f;
+          const float dy = (c0 + j + 1 < W) ? (j == PXL - 1 ? xr_last : xo[j + 1]) - xo[j] : 0.f;
+          gacc += (double)__builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
+        }
+      }
       if (o >= 0 && o < H) {
         const float* const slr = slab + ((o >> 2) & 1) * (4 * PXL * 64);
         const size_t go = (size_t)o * W;
@@ -393,6 +415,10 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
       PIPE_TICK_SYNC();
     };
     for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
+    if (A.g_out) {
+      const double tot = wave_sum(gacc);
+      if (lane == 0) unsafeAtomicAdd(&A.g_out[chain], (double)A.g_scale * tot);
+    }
   }
 }
 

@@ -28,7 +28,7 @@ def build(la, kind, shape, rng):
     img[shape[0] // 4:shape[0] // 2, shape[1] // 4:3 * shape[1] // 4] = 150.0
     img += np.linspace(0, 30, shape[1])[None, :]
     mask, h, off = None, None, None
-    if kind in ("tv", "l2"):
+    if kind in ("tv", "tv10", "l2"):
         h, off = np.ones((5, 5)) / 25, (2, 2)
         y = O.blur(img, h, off) + rng.normal(0, sigma, shape)
         pf = la.L2(Op=la.Convolve2D(shape, h, offset=off), b=y, sigma=1 / sigma ** 2)
@@ -37,8 +37,9 @@ def build(la, kind, shape, rng):
         y = mask * (img + rng.normal(0, sigma, shape))
         pf = la.L2(Op=la.Diagonal(mask, dims=shape), b=y, sigma=1 / sigma ** 2, dims=shape)
     gamma = sigma ** 2
-    if kind == "tv":
-        pg, prior = la.TV(shape, sigma=0.3, niter=5), {"kind": "tv", "sigma": 0.3, "niter": 5, "t": gamma}
+    if kind in ("tv", "tv10"):
+        K = 10 if kind == "tv10" else 5
+        pg, prior = la.TV(shape, sigma=0.3, niter=K), {"kind": "tv", "sigma": 0.3, "niter": K, "t": gamma}
     elif kind == "l2":
         pg, prior = la.L2(sigma=0.05), {"kind": "l2", "sigma": 0.05, "t": gamma}
     else:
@@ -46,9 +47,11 @@ def build(la, kind, shape, rng):
     return img, y, h, off, mask, pf, pg, prior, sigma
 
 
-@pytest.mark.parametrize("kind,tau_scale", [("tv", 0.02), ("l2", 0.02), ("haar", 0.02), ("tv", 1.0)])
-def test_mymala_matches_oracle_with_injected_noise(la, kind, tau_scale):
-    shape = (32, 32)
+@pytest.mark.parametrize("kind,tau_scale,shape", [("tv", 0.02, (32, 32)), ("l2", 0.02, (32, 32)), ("haar", 0.02, (32, 32)),
+                                                   ("tv", 1.0, (32, 32)),
+                                                   # wide images: the step kernel returns f(x'), g(x') as by-products
+                                                   ("tv10", 0.02, (24, 160)), ("tv10", 1.0, (20, 264))])
+def test_mymala_matches_oracle_with_injected_noise(la, kind, tau_scale, shape):
     rng = np.random.default_rng(17)
     img, y, h, off, mask, pf, pg, prior, sigma = build(la, kind, shape, rng)
     gamma, tau = sigma ** 2, tau_scale * sigma ** 2
@@ -81,11 +84,13 @@ def test_mymala_matches_oracle_with_injected_noise(la, kind, tau_scale):
     got = smp.get_state().cpu().numpy()
     assert (acc_d[safe] == acc_o[safe]).all(), (acc_d, acc_o)
     assert rel(got[safe], xo[safe]) < 2e-5, rel(got[safe], xo[safe])
-    if tau_scale >= 1.0:
+    if tau_scale >= 1.0 and shape == (32, 32):
         assert (acc_o[safe] < nit).any(), "expected some rejections at this step size"
     else:
         assert (acc_o[safe] > 0).any(), "expected some acceptances at this step size"
     assert smp.iteration == nit
+    if kind == "tv10":
+        assert smp.kernel_name == "myula_step_pipe_kernel"
     smp.close()
 
 
