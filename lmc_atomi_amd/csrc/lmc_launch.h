@@ -53,6 +53,7 @@ bool rows_supported(const StepArgs& a);
 hipError_t launch_step_rows(StepArgs a, hipStream_t st);
 // taps re-centred for the full-width kernels: returns KT (5 or 7) and fills uc / vc, or 0 (lmc_step_rows.hip)
 int centred_blur_taps(const StepArgs& a, float* uc, float* vc);
+int centred_blur_taps(const BlurTaps& T, float* uc, float* vc);
 // TV stages spread over the waves of a workgroup, one wave = full image width (lmc_step_pipe.hip)
 bool pipe_supported(const StepArgs& a);
 hipError_t launch_step_pipe(StepArgs a, hipStream_t st);

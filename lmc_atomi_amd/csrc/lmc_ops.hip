@@ -308,11 +308,95 @@ __global__ __launch_bounds__(256) void energy_kernel(const float* __restrict__ x
   }
 }
 
+// Separable, centred blur (KT = 5 or 7 taps: every kernel of the reference's experiments): one workgroup = one 32 x 64 tile of
+// one image; the tile plus a halo of HW (+1 row / column for the TV differences) is staged in LDS once, the blur runs as a
+// horizontal and a vertical 1-D pass, the other terms read the same LDS tile.  ~6x faster than the direct 2-D loop above.
+constexpr int kEnTH = 32, kEnTW = 64;
+template <int KT>
+__global__ __launch_bounds__(256) void energy_sep_kernel(const float* __restrict__ x, EnergyArgs E, int tiles_x, int tiles_y,
+                                                         double* __restrict__ f_out, double* __restrict__ g_out) {
+  constexpr int HW = (KT - 1) / 2, HL = HW > 1 ? HW : 1;
+  constexpr int PW = kEnTW + 2 * HL, PH = kEnTH + 2 * HL;
+  __shared__ float xs[PH * PW];
+  __shared__ float hs[PH * kEnTW];
+  __shared__ double scratch[4];
+  const int H = E.H, W = E.W;
+  const size_t img = (size_t)H * W;
+  const int tiles = tiles_x * tiles_y;
+  const int im = blockIdx.x / tiles, tile = blockIdx.x - im * tiles;
+  const int ty0 = (tile / tiles_x) * kEnTH, tx0 = (tile % tiles_x) * kEnTW;
+  const float* __restrict__ xi = x + (size_t)im * img;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < PH * PW; e += 256) {
+    const int r = e / PW, c = e - r * PW;
+    const int gr = ty0 - HL + r, gc = tx0 - HL + c;
+    xs[e] = (gr >= 0 && gr < H && gc >= 0 && gc < W) ? xi[(size_t)gr * W + gc] : 0.f;
+  }
+  __syncthreads();
+  const float* __restrict__ uv = E.blur.h;   // centred: u[0..KT) then v[0..KT) at h[kMaxBlur..]
+  for (int e = tid; e < PH * kEnTW; e += 256) {   // horizontal pass, all staged rows: hx[r][c] = sum_b v[b] x[r][c + HW - b]
+    const int r = e / kEnTW, c = e - r * kEnTW;
+    float acc = 0.f;
+#pragma unroll
+    for (int b = 0; b < KT; ++b) acc = fmaf(uv[kMaxBlur + b], xs[r * PW + HL + c + HW - b], acc);
+    hs[e] = acc;
+  }
+  __syncthreads();
+  double fa = 0.0, ga = 0.0, na = 0.0;
+  const int tx = tid & (kEnTW - 1), tq = tid / kEnTW;      // column, row group (8 rows each)
+  const int gc = tx0 + tx;
+  if (gc < W) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int lr = tq * 8 + j, gr = ty0 + lr;
+      if (gr >= H) break;
+      float acc = 0.f;
+#pragma unroll
+      for (int a = 0; a < KT; ++a) acc = fmaf(uv[a], hs[(HL + lr + HW - a) * kEnTW + tx], acc);
+      const float res = acc - E.y[(size_t)gr * W + gc];
+      fa += (double)res * (double)res;
+      const float v = xs[(HL + lr) * PW + HL + tx];
+      const float dx = (gr + 1 < H) ? xs[(HL + lr + 1) * PW + HL + tx] - v : 0.f;
+      const float dy = (gc + 1 < W) ? xs[(HL + lr) * PW + HL + tx + 1] - v : 0.f;
+      if (E.ncvx_kind == LMC_NCVX_MC_TV) {
+        const float e = sqrtf(fmaf(dx, dx, dy * dy));
+        na += e <= E.ncvx_gamma ? 0.5 * (double)e * e / E.ncvx_gamma : (double)e - 0.5 * E.ncvx_gamma;
+      }
+      if (E.prior_kind == LMC_PRIOR_TV_ISO) ga += (double)sqrtf(fmaf(dx, dx, dy * dy));
+      else if (E.prior_kind == LMC_PRIOR_TV_ANISO) ga += (double)fabsf(dx) + (double)fabsf(dy);
+      else if (E.prior_kind == LMC_PRIOR_L1) ga += (double)fabsf(v);
+      else if (E.prior_kind == LMC_PRIOR_L2) ga += 0.5 * (double)v * (double)v;
+    }
+  }
+  const double ft = block_sum(fa, scratch);
+  __syncthreads();
+  const double gt = block_sum(ga, scratch);
+  __syncthreads();
+  const double nt = E.ncvx_kind != LMC_NCVX_NONE ? block_sum(na, scratch) : 0.0;
+  if (threadIdx.x == 0) {
+    if (f_out) unsafeAtomicAdd(&f_out[im], 0.5 * (double)E.sigma_f * ft - (double)E.ncvx_lambda * nt);
+    if (g_out) unsafeAtomicAdd(&g_out[im], (double)E.prior_sigma * gt);
+  }
+}
+
 hipError_t launch_energies(const float* x, int64_t n_img, const EnergyArgs& E, double* f_out, double* g_out,
                            hipStream_t st) {
   hipError_t e;
   if (f_out && (e = hipMemsetAsync(f_out, 0, sizeof(double) * n_img, st)) != hipSuccess) return e;
   if (g_out && (e = hipMemsetAsync(g_out, 0, sizeof(double) * n_img, st)) != hipSuccess) return e;
+  if (E.data_kind == LMC_DATA_BLUR) {
+    float uc[kMaxBlur] = {0}, vc[kMaxBlur] = {0};
+    const int KT = centred_blur_taps(E.blur, uc, vc);
+    const int tiles_x = (E.W + kEnTW - 1) / kEnTW, tiles_y = (E.H + kEnTH - 1) / kEnTH;
+    if (KT != 0 && (long long)tiles_x * tiles_y * n_img < 0x7fffffffLL) {
+      EnergyArgs S = E;
+      for (int i = 0; i < kMaxBlur; ++i) { S.blur.h[i] = i < KT ? uc[i] : 0.f; S.blur.h[kMaxBlur + i] = i < KT ? vc[i] : 0.f; }
+      const dim3 grid((unsigned)((long long)tiles_x * tiles_y * n_img));
+      if (KT == 5) hipLaunchKernelGGL(energy_sep_kernel<5>, grid, dim3(256), 0, st, x, S, tiles_x, tiles_y, f_out, g_out);
+      else hipLaunchKernelGGL(energy_sep_kernel<7>, grid, dim3(256), 0, st, x, S, tiles_x, tiles_y, f_out, g_out);
+      return hipGetLastError();
+    }
+  }
   const size_t img = (size_t)E.H * E.W;
   int gx = (int)((img + 255) / 256);
   if (gx > 64) gx = 64;

@@ -243,13 +243,14 @@ static bool rows_centre(const float* u, int n, int off, int KT, float* out) {
   return true;
 }
 
-int centred_blur_taps(const StepArgs& a, float* uc, float* vc) {
+int centred_blur_taps(const BlurTaps& T, float* uc, float* vc) {
   float u[kMaxBlur] = {0}, v[kMaxBlur] = {0};
-  if (a.blur.kh > 7 || a.blur.kw > 7 || !separate_blur_taps(a.blur, u, v)) return 0;
+  if (T.kh > 7 || T.kw > 7 || !separate_blur_taps(T, u, v)) return 0;
   for (int KT = 5; KT <= 7; KT += 2)
-    if (rows_centre(u, a.blur.kh, a.blur.oy, KT, uc) && rows_centre(v, a.blur.kw, a.blur.ox, KT, vc)) return KT;
+    if (rows_centre(u, T.kh, T.oy, KT, uc) && rows_centre(v, T.kw, T.ox, KT, vc)) return KT;
   return 0;
 }
+int centred_blur_taps(const StepArgs& a, float* uc, float* vc) { return centred_blur_taps(a.blur, uc, vc); }
 
 bool rows_supported(const StepArgs& a) {
   if (a.data_kind != LMC_DATA_BLUR || a.ncvx_kind != LMC_NCVX_NONE) return false;
