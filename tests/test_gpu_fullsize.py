@@ -1,0 +1,125 @@
+"""Properties at the BASELINE sizes (512x512 x 1024 chains, 256x256 x 128 chains, 512x512 inpainting): too large for the
+oracle to replay in full, so the checks are size-independent -- a chain of the big batch equals the same chain run alone
+(sharding invariance: noise keyed by the global chain id), one chain / one step equals the oracle, moments equal the sum over
+chains of the states, and every kernel variant that covers the configuration agrees."""
+import numpy as np
+import pytest
+
+from oracle import lmc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+    assert torch.cuda.is_available()
+    import lmc_atomi_amd as la
+    yield la
+    la.set_step_variant("auto")
+
+
+def scene(shape, seed=1234):
+    rng = np.random.default_rng(seed)
+    ny, nx = shape
+    img = np.zeros(shape)
+    for _ in range(12):
+        i0, j0 = rng.integers(0, ny - 8), rng.integers(0, nx - 8)
+        i1, j1 = rng.integers(i0 + 4, ny + 1), rng.integers(j0 + 4, nx + 1)
+        img[i0:i1, j0:j1] = rng.uniform(20, 235)
+    img += np.linspace(0, 20, nx)[None, :]
+    return np.clip(img, 0, 255)
+
+
+CASES = [
+    ("config3_tv", (512, 512), 1024, "blur", "tv"),        # BASELINE config 3: deblur + isotropic TV, 1024 chains
+    ("config2_l2", (256, 256), 128, "blur", "l2"),         # BASELINE config 2: deblur + l2 prior, 128 chains
+    ("config5_haar", (512, 512), 512, "mask", "haar"),     # BASELINE config 5 shape: inpainting mask + Haar-l1 (chains of one GPU)
+]
+
+
+@pytest.mark.parametrize("name,shape,C,data,prior", CASES)
+def test_fullsize_properties(la, name, shape, C, data, prior):
+    import torch
+    sigma, tau_reg = 0.75, 0.3
+    gamma, tau = sigma ** 2, 0.2 * sigma ** 2
+    img = scene(shape)
+    rng = np.random.default_rng(0)
+    h, off, mask = None, None, None
+    if data == "blur":
+        h, off = np.ones((5, 5)) / 25, (2, 2)
+        y = O.blur(img, h, off) + rng.normal(0, sigma, shape)
+        pf = la.L2(Op=la.Convolve2D(shape, h, offset=off), b=y, sigma=1 / sigma ** 2)
+    else:
+        mask = (np.random.default_rng(7).uniform(size=shape) < 0.5).astype(np.float64)
+        y = mask * (img + rng.normal(0, sigma, shape))
+        pf = la.L2(Op=la.Diagonal(mask, dims=shape), b=y, sigma=1 / sigma ** 2, dims=shape)
+    if prior == "tv":
+        pg, op = la.TV(shape, sigma=tau_reg, niter=10), {"kind": "tv", "sigma": tau_reg, "niter": 10, "t": gamma}
+    elif prior == "l2":
+        pg, op = la.L2(sigma=0.05), {"kind": "l2", "sigma": 0.05, "t": gamma}
+    else:
+        pg, op = la.WaveletL1(shape, sigma=tau_reg), {"kind": "haar", "sigma": tau_reg, "t": gamma}
+    seed, nit, base = 11, 3, 4096
+    big = la.MYULASampler(pf, pg, shape, n_chains=C, tau=tau, gamma=gamma, seed=seed, chain_offset=base, moments=True)
+    big.set_state(np.zeros(shape, dtype=np.float32))                    # x0 = 0 (prox_lmc_deconv.py:135)
+    big.step(nit)
+    xb = big.get_state()
+    # (1) sharding invariance, exact: chains picked from the batch, run alone with their global ids
+    for c in (0, C // 3, C - 1):
+        one = la.MYULASampler(pf, pg, shape, n_chains=1, tau=tau, gamma=gamma, seed=seed, chain_offset=base + c)
+        one.set_state(np.zeros(shape, dtype=np.float32))
+        one.step(nit)
+        assert torch.equal(one.get_state()[0], xb[c]), (name, c)
+        one.close()
+    # (2) the oracle replays one chain of the batch with the device's own Philox field
+    c = C // 2
+    x = np.zeros((1,) + shape)
+    for k in range(nit):
+        xi = O.philox_normals(seed, k, np.array([base + c]), *shape).astype(np.float64)
+        x = O.myula_step(x, y, h, off, 1 / sigma ** 2, tau, gamma, op, xi, mask=mask)
+    assert rel(xb[c].cpu().numpy(), x[0]) < 5e-6 * nit, (name, rel(xb[c].cpu().numpy(), x[0]))
+    # (3) moments = sums over chains and kept iterations; with x0 = 0 and nit steps, recompute the last term from the states
+    s1, s2, n = big.moments()
+    assert n == nit * C
+    big.reset_moments()
+    big.step(1)
+    t1, t2, n1 = big.moments()
+    xs = big.get_state().double()
+    assert n1 == C
+    assert rel(t1.cpu().numpy(), xs.sum(dim=0).cpu().numpy()) < 1e-9
+    assert rel(t2.cpu().numpy(), (xs * xs).sum(dim=0).cpu().numpy()) < 1e-9
+    # (4) per-chain energies are finite and chains differ (independent noise)
+    f, g = big.energies()
+    assert torch.isfinite(f).all() and torch.isfinite(g).all() and f.std() > 0
+    big.close()
+    torch.cuda.empty_cache()
+
+
+def test_fullsize_variants_agree_config3(la):
+    """512x512 TV K=10: the stage-parallel kernel (default), the split kernel and the LDS-tiled kernel on the same 6 chains."""
+    shape = (512, 512)
+    img = scene(shape)
+    rng = np.random.default_rng(3)
+    h = np.ones((5, 5)) / 25
+    y = O.blur(img, h, (2, 2)) + rng.normal(0, 0.75, shape)
+    pf = la.L2(Op=la.Convolve2D(shape, h, offset=(2, 2)), b=y, sigma=1 / 0.75 ** 2)
+    outs = {}
+    for v in ("tile", "split", "auto"):
+        la.set_step_variant(v)
+        smp = la.MYULASampler(pf, la.TV(shape, sigma=0.3, niter=10), shape, n_chains=6, tau=0.1125, gamma=0.5625, seed=2)
+        smp.set_state(img)
+        smp.step(4)
+        outs[v] = smp.get_state().cpu().numpy()
+        if v == "auto":
+            assert smp.kernel_name == "myula_step_pipe_kernel"
+        smp.close()
+    la.set_step_variant("auto")
+    assert rel(outs["split"], outs["tile"]) < 2e-6
+    assert rel(outs["auto"], outs["tile"]) < 2e-6
