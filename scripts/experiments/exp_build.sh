@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts/exp_build.sh <name> <flags...> : builds build/exp_<name>/liblmc.so with extra flags for lmc_step_split.hip (K=10 only)
+# usage: scripts/experiments/exp_build.sh <name> <flags...> : builds build/exp_<name>/liblmc.so with extra flags for lmc_step_split.hip (K=10 only)
 name=$1; shift
 d=build/exp_$name; mkdir -p $d
 for f in lmc_capi lmc_ops lmc_step_tile lmc_step_stream; do cp build/obj/$f.o $d/; done

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts/exp_build_pipe.sh <name> <file-stem> <flags...> : builds build/exp_<name>/liblmc.so with lmc_<stem>.hip recompiled with the given flags
+# usage: scripts/experiments/exp_build_pipe.sh <name> <file-stem> <flags...> : builds build/exp_<name>/liblmc.so with lmc_<stem>.hip recompiled with the given flags
 # (flags replace the default "-fno-slp-vectorize")
 name=$1; stem=$2; shift; shift
 d=build/exp_$name; mkdir -p $d; rm -f $d/*.o
