@@ -224,6 +224,18 @@ hipError_t launch_step(const lmc::StepArgs& A_in, hipStream_t st, const char** n
     if (name) *name = "myula_step_block_kernel";
     return lmc::launch_step_block(A_in, st);
   }
+  if ((v == 0 || v == 5) && A_in.ncvx_kind == LMC_NCVX_MC_TV) {
+    // stencil-free data term + block-local prox + MC-TV term: the block kernel without the term, then one stencil
+    // pass that adds t * lambda * A^T(A x / max(|A x|, gamma)) to its output
+    lmc::StepArgs B = A_in;
+    B.ncvx_kind = LMC_NCVX_NONE;
+    if (lmc::block_supported(B)) {
+      if (name) *name = "myula_step_block_kernel";
+      hipError_t e = lmc::launch_step_block(B, st);
+      if (e != hipSuccess) return e;
+      return lmc::launch_mc_tv_add(A_in.x_in, A_in.x_out, A_in.C, A_in.H, A_in.W, A_in.t * A_in.ncvx_lambda, A_in.ncvx_gamma, st);
+    }
+  }
   if (v == 5) return hipErrorInvalidConfiguration;
   lmc::StepArgs A = A_in;
   if (A.prior_kind == LMC_PRIOR_HAAR_L1) {   // other data terms: the block-wavelet prox first, consumed by the fused step kernel

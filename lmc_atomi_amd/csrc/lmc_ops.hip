@@ -501,6 +501,45 @@ hipError_t launch_haar_value(const float* x, int64_t n_img, int H, int W, float 
   return hipGetLastError();
 }
 
+// ---- out += coef * A^T(A x / max(|A x|, gamma)): the MC-TV term of L2_ncvx_tv (algs.py:273-277) added to an update computed
+// without it (register-block kernel + this pass instead of the row pipeline: inpainting + Haar-l1 + MC-TV) ----------
+__global__ __launch_bounds__(256) void mc_tv_add_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W,
+                                                        int tiles_x, int tiles_y, float coef, float gamma) {
+  constexpr int TH = 32, TW = 64, PW = TW + 2, PH = TH + 2;
+  __shared__ float xs[PH * PW];
+  const size_t img = (size_t)H * W;
+  const int tiles = tiles_x * tiles_y;
+  const int im = blockIdx.x / tiles, tile = blockIdx.x - im * tiles;
+  const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+  const float* __restrict__ xi = x + (size_t)im * img;
+  float* __restrict__ oi = out + (size_t)im * img;
+  for (int e = threadIdx.x; e < PH * PW; e += 256) {
+    const int r = e / PW, c = e - r * PW;
+    const int gr = ty0 - 1 + r, gc = tx0 - 1 + c;
+    xs[e] = (gr >= 0 && gr < H && gc >= 0 && gc < W) ? xi[(size_t)gr * W + gc] : 0.f;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & (TW - 1), tq = threadIdx.x / TW;
+  const int gc = tx0 + tx;
+  if (gc >= W) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int lr = tq * 8 + j, gr = ty0 + lr;
+    if (gr >= H) break;
+    const float* p = xs + (lr + 1) * PW + tx + 1;
+    const float g = mc_tv_grad(p[-PW], p[-PW + 1], p[-1], p[0], p[1], p[PW - 1], p[PW], gr > 0, gr + 1 < H, gc > 0, gc + 1 < W, gamma);
+    oi[(size_t)gr * W + gc] = fmaf(coef, g, oi[(size_t)gr * W + gc]);
+  }
+}
+
+hipError_t launch_mc_tv_add(const float* x, float* out, int64_t n_img, int H, int W, float coef, float gamma, hipStream_t st) {
+  const int tiles_x = (W + 63) / 64, tiles_y = (H + 31) / 32;
+  const long long nb = (long long)tiles_x * tiles_y * n_img;
+  if (nb > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+  hipLaunchKernelGGL(mc_tv_add_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, out, H, W, tiles_x, tiles_y, coef, gamma);
+  return hipGetLastError();
+}
+
 // ---- noise dump: the field xi[C][H][W] the step kernels draw at `iteration` -----------------
 __global__ __launch_bounds__(256) void noise_kernel(float* __restrict__ out, int C, int H, int W, uint32_t key0,
                                                     uint32_t key1, uint32_t iteration, uint32_t chain_offset) {
