@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--data", default="blur", choices=["blur", "identity", "mask"], help="data term (experiments)")
     ap.add_argument("--ncvx", default="none", choices=["none", "mc", "me"],
                     help="add the L2_ncvx_tv Moreau-difference term (lamda=0.3, gamma=15; SURVEY 8(d) C5)")
+    ap.add_argument("--ncvx-iters", type=int, default=None, help="inner TV-prox iterations of the ME-TV term (default: --tv-iters; the reference uses niter_l2 = 50)")
     ap.add_argument("--noise", default="philox", choices=["philox", "none"], help="noise source (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chains", type=int, default=4)
@@ -123,7 +124,7 @@ def main():
         pf = la.L2(b=y, sigma=1 / sigma ** 2, dims=(H, W))
     if args.ncvx != "none":                          # prox_lmc_deconv.py:106-113 (niter of the inner TV prox = --tv-iters)
         pf = la.L2_ncvx_tv(dims=(H, W), Op=pf.Op, Op2=la.Gradient((H, W)) if args.ncvx == "mc" else None, b=pf.b, sigma=1 / sigma ** 2,
-                           lamda=tau_reg, gamma=15.0, isotropic=True, niter=args.tv_iters)
+                           lamda=tau_reg, gamma=15.0, isotropic=True, niter=args.ncvx_iters or args.tv_iters)
     pg = {"tv": lambda: la.TV((H, W), sigma=tau_reg, niter=args.tv_iters), "l2": lambda: la.L2(sigma=0.05),
           "l1": lambda: la.L1(sigma=tau_reg), "haar": lambda: la.WaveletL1((H, W), sigma=tau_reg)}[args.prior]()
     if args.alg == "ulpda":      # prox_lmc_deconv.py:88-90,455-457: tau0 = 0.95 sigma^2, mu0 = 1, theta = 1, gfirst = False
@@ -197,7 +198,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{H}x{W} MYULA " + {"blur": f"deblur (5x5 uniform box blur, sigma={sigma})", "mask": "inpainting (60 % mask)",
-                                                   "identity": "denoise"}[args.data] + f" + {prior_desc}" + ({"none": "", "mc": " - MC-TV term (lamda=0.3, gamma=15)", "me": f" - ME-TV term (lamda=0.3, gamma=15, {args.tv_iters} inner its)"}[args.ncvx]) + ", "
+                                                   "identity": "denoise"}[args.data] + f" + {prior_desc}" + ({"none": "", "mc": " - MC-TV term (lamda=0.3, gamma=15)", "me": f" - ME-TV term (lamda=0.3, gamma=15, {args.ncvx_iters or args.tv_iters} inner its)"}[args.ncvx]) + ", "
                             f"{C} chains/GPU x {world} GPU, Philox noise, x0=0, "
                             + ("no moments" if args.no_moments else f"posterior moments every {args.thin} it"),
                 "image": [H, W], "chains_per_gpu": C, "chains_total": C * world, "tv_iters": args.tv_iters,

@@ -252,9 +252,12 @@ hipError_t launch_step(const lmc::StepArgs& A_in, hipStream_t st, const char** n
   }
   if (v == 6) return hipErrorInvalidConfiguration;
   // TV K = 10 on a 264..512-wide image with a separable blur: the stage-parallel full-width pipeline
-  if ((v == 0 || v == 7) && lmc::pipe_supported(A)) {
-    if (name) *name = "myula_step_pipe_kernel";
-    return lmc::launch_step_pipe(A, st);
+  if (v == 0 || v == 7) {
+    const int links = lmc::pipe_links(A);
+    if (links == 1 || (links > 1 && state0 && state1)) {
+      if (name) *name = "myula_step_pipe_kernel";
+      return lmc::launch_step_pipe(A, st, state0, state1);
+    }
   }
   if (v == 7) return hipErrorInvalidConfiguration;
   // auto: split pipeline when it covers the configuration (W <= 512); for wider images the tiled kernels:

@@ -56,8 +56,9 @@ hipError_t launch_step_rows(StepArgs a, hipStream_t st);
 int centred_blur_taps(const StepArgs& a, float* uc, float* vc);
 int centred_blur_taps(const BlurTaps& T, float* uc, float* vc);
 // TV stages spread over the waves of a workgroup, one wave = full image width (lmc_step_pipe.hip)
-bool pipe_supported(const StepArgs& a);
-hipError_t launch_step_pipe(StepArgs a, hipStream_t st);
+bool pipe_supported(const StepArgs& a);                  // one launch covers it (10 dual iterations)
+int pipe_links(const StepArgs& a);                       // launches needed (20 .. 60 iterations: chained through HBM state), 0 = not covered
+hipError_t launch_step_pipe(StepArgs a, hipStream_t st, float* state0 = nullptr, float* state1 = nullptr);
 // split streaming variant: the same pipeline over two wave groups (lmc_step_split.hip)
 bool split_supported(const StepArgs& a);
 hipError_t launch_step_split(StepArgs a, hipStream_t st);

@@ -30,12 +30,16 @@ struct PipeGeom {
   static constexpr int NT = K / 2;                              // TV waves (two stages each)
 };
 
-template <int K, int PXL>
+template <int K, int PXL, bool CHAIN = false>
 struct PipeLds {
   static constexpr int BW = 64 * PXL;
   static constexpr int o_x = 0;                                        // [RB][BW]
   static constexpr int o_hand = o_x + PipeGeom<K>::RB * BW;            // [NT][2][4][BW]: rr, ss, p, q of the wave's last stage
-  static constexpr int o_g = o_hand + PipeGeom<K>::NT * 2 * 4 * BW;    // [2][BW] gradient of the output row
+  // chained launches (more than K dual iterations): the last boundary (T_NT -> C) carries rr, ss only, [2][2][BW], and the 8*BW
+  // saved hold the dual state of the previous launch for stage 1, [2][4][BW] (LDS budget: 160 KB)
+  static constexpr int o_hand_last = o_hand + (PipeGeom<K>::NT - 1) * 8 * BW;
+  static constexpr int o_hand0 = o_hand_last + 4 * BW;
+  static constexpr int o_g = CHAIN ? o_hand0 + 8 * BW : o_hand + PipeGeom<K>::NT * 2 * 4 * BW;    // [2][BW] gradient of the output row
   static constexpr int o_slab = o_g + 2 * BW;                          // [2][4][PXL][64] normals of this and the next quad row-group
   static constexpr int total = o_slab + 2 * 4 * PXL * 64;
 };
@@ -127,11 +131,14 @@ __device__ __forceinline__ void gload_row(float (&dst)[PXL], const float* __rest
   }
 }
 
-template <int K, int PXL, int KT>
-__global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step_pipe_kernel(const StepArgs A) {
+// KT = 0: no data term (pure prox, or t = 0).  CHAIN: the launch is one link of a chain of launches that together run more than K
+// dual iterations: stage 1 starts from the dual state A.tv_in of the previous link ([C][4][H][W]: rr, ss, p, q; NULL = zeros), the last
+// stage's state goes to A.tv_out (NULL = not stored), and with A.tv_state_only the combine / store of x_out is skipped.
+template <int K, int PXL, int KT, bool CHAIN = false>
+__global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void myula_step_pipe_kernel(const StepArgs A) {
   using G = PipeGeom<K>;
-  using L = PipeLds<K, PXL>;
-  constexpr int D = G::D, E = G::E, RB = G::RB, NT = G::NT, BW = L::BW, HW = (KT - 1) / 2;
+  using L = PipeLds<K, PXL, CHAIN>;
+  constexpr int D = G::D, E = G::E, RB = G::RB, NT = G::NT, BW = L::BW, HW = KT > 0 ? (KT - 1) / 2 : 0;
   static_assert(K >= 2 && K % 2 == 0, "two stages per TV wave");
   static_assert(D >= KT + 1, "the blur pipeline reads ring rows at least one tick old");
   extern __shared__ float lds[];
@@ -157,16 +164,29 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
     // the windows of the last KT-1 horizontally filtered rows: with KT = 5 they are rings indexed by (tick & 3), static under the
     // x4 unroll (row i-a in slot (U-a)&3, the new row replaces the oldest); otherwise they are rotated by moves
     constexpr bool kRing4 = (KT == 5);
-    float xpre[4][PXL], hxw[KT - 1][PXL], hrw[KT - 1][PXL], ypre[PXL];
+    constexpr int NWIN = KT > 1 ? KT - 1 : 1;
+    float xpre[4][PXL], hxw[NWIN][PXL], hrw[NWIN][PXL], ypre[PXL];
 #pragma unroll
-    for (int a = 0; a < KT - 1; ++a)
+    for (int a = 0; a < NWIN; ++a)
 #pragma unroll
       for (int k = 0; k < PXL; ++k) { hxw[a][k] = 0.f; hrw[a][k] = 0.f; }
 #pragma unroll
     for (int u = 0; u < 4; ++u) gload_row<PXL>(xpre[u], xin + (size_t)min(u, H - 1) * W, c0, W, u < H);
-    {   // observation row of the first residual row
+    if constexpr (KT > 0) {   // observation row of the first residual row
       const int r = 0 + 1 - D + (KT - 1) - HW;
       gload_row<PXL>(ypre, A.y + (size_t)min(max(r, 0), H - 1) * W, c0, W, r >= 0 && r < H);
+    }
+    // chained launch: the dual state rows for stage 1, fetched two ticks ahead (row t - E - 1 is published at tick t)
+    float spre[CHAIN ? 2 : 1][CHAIN ? 4 : 1][CHAIN ? PXL : 1];
+    const float* const sin = CHAIN && A.tv_in ? A.tv_in + (size_t)chain * 4 * img : nullptr;
+    if constexpr (CHAIN) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int rs = u - E - 1;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          gload_row<PXL>(spre[u][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H);
+      }
     }
     double facc = 0.0;        // sum of squared residuals (A.f_out)
     auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
@@ -178,6 +198,16 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
         prow_store<PXL>(ring_row(t), lane, xv);
         gload_row<PXL>(xpre[U], xin + (size_t)min(t + 4, H - 1) * W, c0, W, t + 4 < H);
       }
+      if constexpr (CHAIN) {   // dual state row t - E - 1 of the previous link -> stage 1's hand-off slot P (read next tick)
+        float* hb = lds + L::o_hand0 + P * 4 * BW;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) prow_store<PXL>(hb + f * BW, lane, spre[P][f]);
+        const int rs = t + 2 - E - 1;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          gload_row<PXL>(spre[P][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H);
+      }
+      if constexpr (KT > 0) {
       const int i = t + 1 - D + (KT - 1);       // blur input row (<= t-1: published in an earlier tick)
       float hxn[PXL];
       {
@@ -247,6 +277,7 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
         }
         prow_store<PXL>(lds + L::o_g + P * BW, lane, gout);      // row t + 1 - D, read by C next tick
       }
+      }   // KT > 0
       PIPE_TICK_SYNC();
     };
     for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
@@ -260,8 +291,10 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
     const float gam = A.tv.gamma, cstep = A.tv.c;
     const float beta1 = A.tv.betas[k1 - 1], beta2 = A.tv.betas[k2 - 1];
     const float cr_last = (c0 + PXL - 1 == W - 1) ? 0.f : cstep;     // no horizontal difference across column W-1
-    float* const hout = lds + L::o_hand + (wave - 1) * 8 * BW;       // this wave's hand-off [2][4][BW]
-    const float* const hin = hout - 8 * BW;                          // the previous wave's (unused by wave 1)
+    float* const hout = lds + L::o_hand + (wave - 1) * 8 * BW;       // this wave's hand-off [2][4][BW] ([2][2][BW] for the last one if CHAIN)
+    const bool from_state = CHAIN && wave == 1 && A.tv_in != nullptr;
+    const float* const hin = from_state ? lds + L::o_hand0 : hout - 8 * BW;   // the previous wave's / the previous link's state
+    float* const sout = CHAIN && wave == NT && A.tv_out ? A.tv_out + (size_t)chain * 4 * img : nullptr;
     constexpr int NP = PXL / 2;
     DualRow<NP> inb[2], o1[2];
     v2f sol1[NP], sol2[NP];
@@ -283,14 +316,33 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
         const float cdown = ((unsigned)(a2 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
         DualRow<NP> out;
         pipe_stage<NP>(xk[P], o1[P ^ 1].rr, o1[P ^ 1].ss, o1[P], sol2, gam, cdown, cstep, cr_last, beta2, out);
-        float* hb = hout + P * 4 * BW;
-        pairs_store<NP>(hb, lane, out.rr);
-        pairs_store<NP>(hb + BW, lane, out.ss);
-        pairs_store<NP>(hb + 2 * BW, lane, out.p);
-        pairs_store<NP>(hb + 3 * BW, lane, out.q);
+        if (!CHAIN || wave < NT) {
+          float* hb = hout + P * 4 * BW;
+          pairs_store<NP>(hb, lane, out.rr);
+          pairs_store<NP>(hb + BW, lane, out.ss);
+          pairs_store<NP>(hb + 2 * BW, lane, out.p);
+          pairs_store<NP>(hb + 3 * BW, lane, out.q);
+        } else {
+          float* hb = hout + P * 2 * BW;                   // last boundary of a chained launch: rr, ss for the final primal step ...
+          pairs_store<NP>(hb, lane, out.rr);
+          pairs_store<NP>(hb + BW, lane, out.ss);
+          const int b2 = a2 - 1;                           // ... and the whole dual state of row b2 for the next link
+          if (sout && b2 >= 0 && b2 < H) {
+#pragma unroll
+            for (int g = 0; g < NP / 2; ++g) {
+              if (c0 + 4 * g < W) {
+                float* d = sout + (size_t)b2 * W + c0 + 4 * g;
+                *reinterpret_cast<float4*>(d) = make_float4(out.rr[2 * g].x, out.rr[2 * g].y, out.rr[2 * g + 1].x, out.rr[2 * g + 1].y);
+                *reinterpret_cast<float4*>(d + img) = make_float4(out.ss[2 * g].x, out.ss[2 * g].y, out.ss[2 * g + 1].x, out.ss[2 * g + 1].y);
+                *reinterpret_cast<float4*>(d + 2 * img) = make_float4(out.p[2 * g].x, out.p[2 * g].y, out.p[2 * g + 1].x, out.p[2 * g + 1].y);
+                *reinterpret_cast<float4*>(d + 3 * img) = make_float4(out.q[2 * g].x, out.q[2 * g].y, out.q[2 * g + 1].x, out.q[2 * g + 1].y);
+              }
+            }
+          }
+        }
       }
       {   // stage k1 on row a1: inputs from the previous wave's hand-off (row a1) and the one read a tick earlier (row a1-1)
-        if (k1 > 1) {
+        if (k1 > 1 || from_state) {
           const float* hb = hin + (P ^ 1) * 4 * BW;
           pairs_load<NP>(inb[P].rr, hb, lane);
           pairs_load<NP>(inb[P].ss, hb + BW, lane);
@@ -313,7 +365,7 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
       constexpr int U = decltype(uu)::value;
       constexpr int NI = ((U - D) % 4 + 4) % 4;        // == o & 3  (t = 4m + U)
       const int o = t - D;
-      if (A.noise_mode == LMC_NOISE_PHILOX) {
+      if (A.noise_mode == LMC_NOISE_PHILOX && !(CHAIN && A.tv_state_only)) {
         const int qn = ((o - NI) >> 2) + 1;             // quad row-group being prepared (o - NI is a multiple of 4)
         if (qn >= 0 && 4 * qn < H) {
           float* const sl = slab + (qn & 1) * (4 * PXL * 64);
@@ -333,7 +385,8 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
   } else {
     // ---------------- C: final primal step, combine, store --------------------------------------------------
     const float gam = A.tv.gamma;
-    const float* const hin = lds + L::o_hand + (NT - 1) * 8 * BW;
+    const float* const hin = lds + L::o_hand + (NT - 1) * 8 * BW;      // [2][4][BW], or [2][2][BW] in a chained launch
+    constexpr int HSTR = CHAIN ? 2 * BW : 4 * BW;
     float* const slab = lds + L::o_slab + lane;        // normal (row q of the quad, pixel k) at slab[(q*PXL + k)*64]
     double gacc = 0.0;        // sum |grad x_in| (A.g_out)
     float crr[2][PXL], xprev[PXL];
@@ -343,9 +396,10 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
       constexpr int U = decltype(uu)::value, P = U & 1;
       constexpr int NI = ((U - D) % 4 + 4) % 4;        // == o & 3  (t = 4m + U)
       const int o = t - D;
+      if (CHAIN && A.tv_state_only) { PIPE_TICK_SYNC(); return; }     // this link only advances the dual state
       float css[PXL], xo[PXL], gv[PXL], prox[PXL];
-      prow_load<PXL>(crr[P], hin + (P ^ 1) * 4 * BW, lane);          // rr^K on row o (written last tick)
-      prow_load<PXL>(css, hin + (P ^ 1) * 4 * BW + BW, lane);
+      prow_load<PXL>(crr[P], hin + (P ^ 1) * HSTR, lane);            // rr^K on row o (written last tick)
+      prow_load<PXL>(css, hin + (P ^ 1) * HSTR + BW, lane);
       prow_load<PXL>(xo, ring_row(o), lane);
       prow_load<PXL>(gv, lds + L::o_g + (P ^ 1) * BW, lane);
       const float ssl0 = dpp_from_left(css[PXL - 1], 0.f);
@@ -424,41 +478,78 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), PXL == 8 ? 1 : 2) void myula_step
 
 int centred_blur_taps(const StepArgs& a, float* uc, float* vc);   // lmc_step_rows.hip
 
-template <int K, int PXL, int KT>
-static constexpr size_t pipe_lds_bytes() { return sizeof(float) * (size_t)PipeLds<K, PXL>::total; }
+template <int K, int PXL, int KT, bool CHAIN = false>
+static constexpr size_t pipe_lds_bytes() { return sizeof(float) * (size_t)PipeLds<K, PXL, CHAIN>::total; }
 
-bool pipe_supported(const StepArgs& a) {
-  if (a.prior_kind != LMC_PRIOR_TV_ISO || a.tv.niter != 10) return false;
-  if (a.data_kind != LMC_DATA_BLUR || a.prox_ext) return false;
-  if (a.tv_in || a.tv_out || a.tv_state_only) return false;
+// Number of links a configuration needs (0: not covered): 10 dual iterations per launch; more (20, 30, ... 60) as a chain of
+// launches that hand the dual state (rr, ss, p, q) over in HBM -- exact, the same mechanism as the tile kernel's chunks.
+int pipe_links(const StepArgs& a) {
+  if (a.prior_kind != LMC_PRIOR_TV_ISO || a.tv.niter < 10 || a.tv.niter > kMaxTvIters || a.tv.niter % 10) return 0;
+  if (a.prox_ext || a.tv_in || a.tv_out || a.tv_state_only) return 0;
   // 8 (4) pixels per lane above (up to) 256 columns; narrower than 129 columns half the lanes idle and the split kernel wins
-  if (a.W > 512 || a.W <= 128 || (a.W & (a.W > 256 ? 7 : 3)) || a.H < 1) return false;
-  float uc[kMaxBlur], vc[kMaxBlur];
-  return centred_blur_taps(a, uc, vc) != 0;
+  if (a.W > 512 || a.W <= 128 || (a.W & (a.W > 256 ? 7 : 3)) || a.H < 1) return 0;
+  if (a.data_kind == LMC_DATA_BLUR) {
+    float uc[kMaxBlur], vc[kMaxBlur];
+    if (centred_blur_taps(a, uc, vc) == 0) return 0;
+  } else if (a.data_kind != LMC_DATA_NONE) {
+    return 0;                                  // pointwise data terms: split kernel
+  }
+  if (a.data_kind == LMC_DATA_NONE && (a.ncvx_kind != LMC_NCVX_NONE || a.f_out)) return 0;
+  return a.tv.niter / 10;
 }
 
-hipError_t launch_step_pipe(StepArgs a, hipStream_t st) {
-  if (!pipe_supported(a)) return hipErrorInvalidConfiguration;
-  float uc[kMaxBlur] = {0}, vc[kMaxBlur] = {0};
-  const int KT = centred_blur_taps(a, uc, vc);
-  for (int i = 0; i < kMaxBlur; ++i) { a.blur.h[i] = i < KT ? uc[i] : 0.f; a.blur.h[kMaxBlur + i] = i < KT ? vc[i] : 0.f; }
-  auto launch = [&](auto kern, size_t lb, bool& attr_set) -> hipError_t {
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-      if (e != hipSuccess) return e;
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(a.C), dim3(64 * (10 / 2 + 3)), lb, st, a);
-    return hipSuccess;
-  };
-  static bool set5 = false, set7 = false, set45 = false, set47 = false;
-  hipError_t e;
-  if (a.W > 256) e = KT == 5 ? launch(myula_step_pipe_kernel<10, 8, 5>, pipe_lds_bytes<10, 8, 5>(), set5)
-                             : launch(myula_step_pipe_kernel<10, 8, 7>, pipe_lds_bytes<10, 8, 7>(), set7);
-  else e = KT == 5 ? launch(myula_step_pipe_kernel<10, 4, 5>, pipe_lds_bytes<10, 4, 5>(), set45)
-                   : launch(myula_step_pipe_kernel<10, 4, 7>, pipe_lds_bytes<10, 4, 7>(), set47);
-  if (e != hipSuccess) return e;
+bool pipe_supported(const StepArgs& a) { return pipe_links(a) == 1; }
+
+template <int PXL, int KT, bool CHAIN>
+static hipError_t pipe_launch_one(const StepArgs& a, hipStream_t st) {
+  auto kern = myula_step_pipe_kernel<10, PXL, KT, CHAIN>;
+  constexpr size_t lb = pipe_lds_bytes<10, PXL, KT, CHAIN>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.C), dim3(64 * (10 / 2 + 3)), lb, st, a);
   return hipGetLastError();
+}
+
+template <bool CHAIN>
+static hipError_t pipe_dispatch(const StepArgs& a, int KT, hipStream_t st) {
+  if (a.W > 256) {
+    if (KT == 5) return pipe_launch_one<8, 5, CHAIN>(a, st);
+    if (KT == 7) return pipe_launch_one<8, 7, CHAIN>(a, st);
+    return pipe_launch_one<8, 0, CHAIN>(a, st);
+  }
+  if (KT == 5) return pipe_launch_one<4, 5, CHAIN>(a, st);
+  if (KT == 7) return pipe_launch_one<4, 7, CHAIN>(a, st);
+  return pipe_launch_one<4, 0, CHAIN>(a, st);
+}
+
+// state0 / state1: [C][4][H][W] ping-pong buffers for the dual state between links (needed when a.tv.niter > 10)
+hipError_t launch_step_pipe(StepArgs a, hipStream_t st, float* state0, float* state1) {
+  const int links = pipe_links(a);
+  if (links == 0 || (links > 1 && (!state0 || !state1))) return hipErrorInvalidConfiguration;
+  int KT = 0;
+  if (a.data_kind == LMC_DATA_BLUR) {
+    float uc[kMaxBlur] = {0}, vc[kMaxBlur] = {0};
+    KT = centred_blur_taps(a, uc, vc);
+    for (int i = 0; i < kMaxBlur; ++i) { a.blur.h[i] = i < KT ? uc[i] : 0.f; a.blur.h[kMaxBlur + i] = i < KT ? vc[i] : 0.f; }
+  }
+  if (links == 1) return pipe_dispatch<false>(a, KT, st);
+  float* st_buf[2] = {state0, state1};
+  for (int j = 0; j < links; ++j) {
+    StepArgs b = a;
+    b.tv.niter = 10;
+    for (int i = 0; i < 10; ++i) b.tv.betas[i] = a.tv.betas[10 * j + i];
+    b.tv_in = j > 0 ? st_buf[(j - 1) & 1] : nullptr;
+    b.tv_out = j < links - 1 ? st_buf[j & 1] : nullptr;
+    b.tv_state_only = j < links - 1;
+    // the data term, the noise and the energies belong to the last link only; the earlier ones skip the blur pipeline
+    hipError_t e = pipe_dispatch<true>(b, b.tv_state_only ? 0 : KT, st);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 }  // namespace lmc

@@ -98,3 +98,50 @@ def test_pipe_kernel_with_me_tv_term_matches_tile(la):
         smp.close()
     la.set_step_variant("auto")
     assert rel(outs["auto"], outs["tile"]) < 3e-6, rel(outs["auto"], outs["tile"])
+
+
+@pytest.mark.parametrize("shape,K", [((40, 264), 20), ((33, 160), 50), ((21, 512), 30)])
+def test_pipe_chained_launches_long_tv_prox(la, shape, K):
+    """More than 10 dual iterations: a chain of launches handing the dual state (rr, ss, p, q) over in HBM -- the TV prox alone
+    (no data term) against the oracle, and the full update (blur + TV(K) + noise) against the tiled kernel's exact chunks."""
+    rng = np.random.default_rng(31)
+    img, h, off, y = problem(shape, rng)
+    x = img[None] + rng.normal(0, 8, (2,) + shape)
+    la.set_step_variant("auto")
+    tv = la.TV(shape, sigma=0.3, niter=K)
+    got = np.stack([tv.prox(x[i].ravel().copy(), 0.7).reshape(shape) for i in range(2)])
+    want = np.stack([O.tv_prox_fgp(x[i], 0.3 * 0.7, K) for i in range(2)])
+    assert rel(got, want) < 2e-6 * K, rel(got, want)
+    pf = la.L2(Op=la.Convolve2D(shape, h, offset=off), b=y, sigma=1 / 0.75 ** 2)
+    outs = {}
+    for v in ("tile", "pipe"):
+        la.set_step_variant(v)
+        smp = la.MYULASampler(pf, la.TV(shape, sigma=0.3, niter=K), shape, n_chains=2, tau=0.1125, gamma=0.5625, seed=6)
+        smp.set_state(x)
+        smp.step(2)
+        outs[v] = smp.get_state().cpu().numpy()
+        assert v in smp.kernel_name
+        smp.close()
+    la.set_step_variant("auto")
+    assert rel(outs["pipe"], outs["tile"]) < 2e-6 * K, rel(outs["pipe"], outs["tile"])
+
+
+def test_pipe_me_tv_inner_prox_chained(la):
+    """L2_ncvx_tv ME-TV with niter = 20 inner iterations on a wide image: the inner prox runs as two chained launches."""
+    rng = np.random.default_rng(10)
+    shape = (30, 264)
+    img, h, off, y = problem(shape, rng)
+    outs = {}
+    for v in ("tile", "auto"):
+        la.set_step_variant(v)
+        pf = la.L2_ncvx_tv(dims=shape, Op=la.Convolve2D(shape, h, offset=off), b=y.ravel(), sigma=1 / 0.75 ** 2, lamda=0.3, gamma=15.0,
+                           isotropic=True, niter=20)
+        outs[("g", v)] = pf.grad((img + 3.0).ravel())
+        smp = la.MYULASampler(pf, la.TV(shape, sigma=0.3, niter=10), shape, n_chains=2, tau=0.1125, gamma=0.5625, seed=1)
+        smp.set_state(img)
+        smp.step(2)
+        outs[v] = smp.get_state().cpu().numpy()
+        smp.close()
+    la.set_step_variant("auto")
+    assert rel(outs[("g", "auto")], outs[("g", "tile")]) < 1e-5
+    assert rel(outs["auto"], outs["tile"]) < 5e-6
