@@ -121,6 +121,31 @@ __device__ __forceinline__ void pipe_stage(const v2f (&xa)[NP], const v2f (&r1)[
   for (int i = 0; i < NP; ++i) solb[i] = sol[i];
 }
 
+// Stage 1 of a launch that starts from the zero dual state: (rr, ss, p, q)^0 = 0, so sol^1 = x and the differences with the previous
+// iterate vanish.  Bit-identical to pipe_stage() fed with zeros (x - 0 = x, fma(c, d, 0) = c*d), at ~60 % of its instructions.
+template <int NP>
+__device__ __forceinline__ void pipe_stage_first(const v2f (&xa)[NP], v2f (&solb)[NP], float cdown, float cstep, float cr_last, float beta,
+                                                 DualRow<NP>& out) {
+  const float solr_last = dpp_from_right(solb[0].x, 0.f);
+  const v2f ncd = pk_set(-cdown), vb = pk_set(beta);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const v2f solr = v2f{solb[i].y, i == NP - 1 ? solr_last : solb[i + 1].x};
+    const v2f ncr = i == NP - 1 ? v2f{-cstep, -cr_last} : pk_set(-cstep);
+    const v2f r = ncd * (xa[i] - solb[i]);
+    const v2f s = ncr * (solr - solb[i]);
+    const v2f n2 = pk_fma(r, r, s * s);
+    const v2f inv = v2f{__builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(n2.x), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(n2.y), 0.f, 1.f)};
+    const v2f pn = r * inv, qn = s * inv;
+    out.rr[i] = pk_fma(vb, pn, pn);
+    out.ss[i] = pk_fma(vb, qn, qn);
+    out.p[i] = pn;
+    out.q[i] = qn;
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) solb[i] = xa[i];
+}
+
 template <int PXL>
 __device__ __forceinline__ void gload_row(float (&dst)[PXL], const float* __restrict__ row, int c0, int W, bool ok) {
 #pragma unroll
@@ -158,6 +183,9 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
   float* const xring = lds + L::o_x;
   auto ring_row = [&](int row) -> float* { return xring + ((unsigned)(row + RB) % (unsigned)RB) * BW; };   // row >= -RB
 
+#ifdef LMC_EXP_SKIP   // timing experiment (with LMC_EXP_NOBARRIER): the waves in the bitmask leave at once (results are wrong)
+  if ((LMC_EXP_SKIP >> wave) & 1) return;
+#endif
   if (wave == 0) {
     // ---------------- L: loader + blur gradient -------------------------------------------------------------
     const float* __restrict__ uv = A.blur.h;   // centred taps: u[0..KT) then v[0..KT) at h[kMaxBlur..]
@@ -165,16 +193,25 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
     // x4 unroll (row i-a in slot (U-a)&3, the new row replaces the oldest); otherwise they are rotated by moves
     constexpr bool kRing4 = (KT == 5);
     constexpr int NWIN = KT > 1 ? KT - 1 : 1;
-    float xpre[4][PXL], hxw[NWIN][PXL], hrw[NWIN][PXL], ypre[PXL];
+    // x rows: fetched kXPF ticks ahead, slot (tick & 3) (8 ahead was measured: no gain, +50 VGPRs)
+    constexpr int kXPF = 4;
+    float xpre[kXPF][PXL], hxw[NWIN][PXL], hrw[NWIN][PXL], ypre[4][PXL];   // y rows: fetched kYPF ticks ahead, slot (tick & 3)
+    constexpr int kYPF = KT == 7 ? 2 : 3;     // 7 taps: the windows already take 96 registers
 #pragma unroll
     for (int a = 0; a < NWIN; ++a)
 #pragma unroll
       for (int k = 0; k < PXL; ++k) { hxw[a][k] = 0.f; hrw[a][k] = 0.f; }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) gload_row<PXL>(xpre[u], xin + (size_t)min(u, H - 1) * W, c0, W, u < H);
-    if constexpr (KT > 0) {   // observation row of the first residual row
-      const int r = 0 + 1 - D + (KT - 1) - HW;
-      gload_row<PXL>(ypre, A.y + (size_t)min(max(r, 0), H - 1) * W, c0, W, r >= 0 && r < H);
+    for (int u = 0; u < kXPF; ++u) gload_row<PXL>(xpre[u], xin + (size_t)min(u, H - 1) * W, c0, W, u < H);
+    // Vector-memory loads return in order: waiting for a load also waits for every load issued before it.  So the loads a tick
+    // consumes must be the OLDEST in flight: y rows are requested three ticks ahead and, inside a tick, before the x row that is only
+    // needed four ticks later (with y one tick ahead and issued after x, every tick waited for a fresh HBM access: ~2000 cycles).
+    if constexpr (KT > 0) {   // observation rows of the first kYPF residual rows
+#pragma unroll
+      for (int u = 0; u < kYPF; ++u) {
+        const int r = u + 1 - D + (KT - 1) - HW;
+        gload_row<PXL>(ypre[u], A.y + (size_t)min(max(r, 0), H - 1) * W, c0, W, r >= 0 && r < H);
+      }
     }
     // chained launch: the dual state rows for stage 1, fetched two ticks ahead (row t - E - 1 is published at tick t)
     float spre[CHAIN ? 2 : 1][CHAIN ? 4 : 1][CHAIN ? PXL : 1];
@@ -191,12 +228,16 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
     double facc = 0.0;        // sum of squared residuals (A.f_out)
     auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
       constexpr int U = decltype(uu)::value, P = U & 1;
+      if constexpr (KT > 0) {   // observation row of the residual row kYPF ticks from now
+        const int r3 = t + kYPF + 1 - D + (KT - 1) - HW;
+        gload_row<PXL>(ypre[(U + kYPF) & 3], A.y + (size_t)min(max(r3, 0), H - 1) * W, c0, W, r3 >= 0 && r3 < H);
+      }
       {   // row t arrives: publish it in the ring (zeros below the image); fetch row t + 4
         float xv[PXL];
 #pragma unroll
         for (int k = 0; k < PXL; ++k) xv[k] = t < H ? xpre[U][k] : 0.f;
         prow_store<PXL>(ring_row(t), lane, xv);
-        gload_row<PXL>(xpre[U], xin + (size_t)min(t + 4, H - 1) * W, c0, W, t + 4 < H);
+        gload_row<PXL>(xpre[U], xin + (size_t)min(t + kXPF, H - 1) * W, c0, W, t + kXPF < H);
       }
       if constexpr (CHAIN) {   // dual state row t - E - 1 of the previous link -> stage 1's hand-off slot P (read next tick)
         float* hb = lds + L::o_hand0 + P * 4 * BW;
@@ -236,7 +277,7 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
           float acc = uv[0] * hxn[k];
 #pragma unroll
           for (int a = 1; a < KT; ++a) acc = fmaf(uv[a], hxw[kRing4 ? ((U - a) & 3) : a - 1][k], acc);
-          R[k] = (rowok && c0 + (k & ~3) < W) ? acc - ypre[k] : 0.f;
+          R[k] = (rowok && c0 + (k & ~3) < W) ? acc - ypre[U & 3][k] : 0.f;
         }
         if (A.f_out) {
 #pragma unroll
@@ -249,8 +290,7 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
             for (int k = 0; k < PXL; ++k) hxw[a][k] = hxw[a - 1][k];
         }
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) hxw[kRing4 ? U : 0][k] = hxn[k];
-        gload_row<PXL>(ypre, A.y + (size_t)min(max(r + 1, 0), H - 1) * W, c0, W, r + 1 >= 0 && r + 1 < H);
+        for (int k = 0; k < PXL; ++k) hxw[kRing4 ? (U & 3) : 0][k] = hxn[k];
       }
       {   // horizontal adjoint, then G[r - HW] = sum_a u[a] hR[r - 2HW + a]
         float e[PXL + 2 * HW], gout[PXL];
@@ -272,7 +312,7 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
 #pragma unroll
             for (int a = KT - 2; a >= 1; --a) hrw[a][k] = hrw[a - 1][k];
           }
-          hrw[kRing4 ? U : 0][k] = hrn;
+          hrw[kRing4 ? (U & 3) : 0][k] = hrn;
           gout[k] = A.sigma_f * acc;
         }
         prow_store<PXL>(lds + L::o_g + P * BW, lane, gout);      // row t + 1 - D, read by C next tick
@@ -287,6 +327,10 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
     }
   } else if (wave <= NT) {
     // ---------------- T: TV stages k1 = 2*wave - 1 and k2 = 2*wave -----------------------------------------
+    // Wave 1 of a launch that starts from the zero dual state runs a specialised stage 1 (its own copy of the loop, no branch inside):
+    // it shares a SIMD with wave 5, and two full T waves on one SIMD are what bounds the tick.
+    auto t_role = [&](auto first_tag) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
     const int k1 = 2 * wave - 1, k2 = 2 * wave;
     const float gam = A.tv.gamma, cstep = A.tv.c;
     const float beta1 = A.tv.betas[k1 - 1], beta2 = A.tv.betas[k2 - 1];
@@ -342,20 +386,26 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
         }
       }
       {   // stage k1 on row a1: inputs from the previous wave's hand-off (row a1) and the one read a tick earlier (row a1-1)
-        if (k1 > 1 || from_state) {
-          const float* hb = hin + (P ^ 1) * 4 * BW;
-          pairs_load<NP>(inb[P].rr, hb, lane);
-          pairs_load<NP>(inb[P].ss, hb + BW, lane);
-          pairs_load<NP>(inb[P].p, hb + 2 * BW, lane);
-          pairs_load<NP>(inb[P].q, hb + 3 * BW, lane);
+        if constexpr (!FIRST) {
+          if (k1 > 1 || from_state) {
+            const float* hb = hin + (P ^ 1) * 4 * BW;
+            pairs_load<NP>(inb[P].rr, hb, lane);
+            pairs_load<NP>(inb[P].ss, hb + BW, lane);
+            pairs_load<NP>(inb[P].p, hb + 2 * BW, lane);
+            pairs_load<NP>(inb[P].q, hb + 3 * BW, lane);
+          }
         }
         pairs_load<NP>(xk[P], ring_row(a1), lane);      // read two ticks ago as row a1 = this tick's a2: consumed above
         const float cdown = ((unsigned)(a1 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
-        pipe_stage<NP>(xk[P], inb[P].rr, inb[P].ss, inb[P ^ 1], sol1, gam, cdown, cstep, cr_last, beta1, o1[P]);
+        if constexpr (FIRST) pipe_stage_first<NP>(xk[P], sol1, cdown, cstep, cr_last, beta1, o1[P]);
+        else pipe_stage<NP>(xk[P], inb[P].rr, inb[P].ss, inb[P ^ 1], sol1, gam, cdown, cstep, cr_last, beta1, o1[P]);
       }
       PIPE_TICK_SYNC();
     };
     for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
+    };   // t_role
+    if (!CHAIN && wave == 1) t_role(std::true_type{});
+    else t_role(std::false_type{});
   } else if (wave == NT + 2) {
     // ---------------- N: Philox normals, one quad row-group ahead of C -------------------------------------
     // In the tick of row 4q + NI the normals of pixels NI*PXL/4 .. of quad q + 1 are drawn into the other half of the slab
