@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   constexpr bool kNzLds = PXL == 8;
   __shared__ float nz_lds[kNzLds ? 4 * PXL * 4 * 64 : 1];
   float* const nzw = nz_lds + (kNzLds ? (threadIdx.x >> 6) * PXL * 4 * 64 + lane : 0);
-  float xr[8][PXL], A[8][PXL], G[8][PXL], nz[kNzLds ? 1 : PXL][4], yq[2][PXL];
+  float xr[8][PXL], A[8][PXL], G[8][PXL], nz[kNzLds ? 1 : PXL][4], yq[4][PXL];
 #pragma unroll
   for (int s = 0; s < 8; ++s)
 #pragma unroll
@@ -82,10 +82,15 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
     rows_load<PXL>(xr[(8 - LAG + p) & 7], xin + (size_t)max(i, 0) * W, c0, W, i >= 0 && i < H);
   });
 
-  {   // observation row of the first step (row i_first - HW; J = 8 - LAG is even)
-    const int r = i_first - HW;
-    rows_load<PXL>(yq[0], P.y + (size_t)max(r, 0) * W, c0, W, r >= 0 && r < H);
-  }
+  // Vector-memory loads return in order, so the load a step consumes must be older than the x rows still in flight for later steps:
+  // the observation row is requested kYD steps ahead and first in its step (one step ahead and after the x prefetch, every step
+  // waited for an HBM access issued one step earlier).
+  constexpr int kYD = 2;
+  static_for<0, kYD>([&](auto dd) {   // observation rows of the first kYD steps (residual rows i_first - HW + d, slot (J & 3))
+    constexpr int d = decltype(dd)::value;
+    const int r = i_first + d - HW;
+    rows_load<PXL>(yq[(8 - LAG + d) & 3], P.y + (size_t)min(max(r, 0), H - 1) * W, c0, W, r >= 0 && r < H);
+  });
 
   double dacc = 0.0;       // sum x_in * x_out over this wave's band (P.dot_out: the p.Ap of CG)
 
@@ -94,8 +99,8 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   auto step = [&](auto jj, const int base) __attribute__((always_inline)) {
     constexpr int J = decltype(jj)::value;
     const int i = base + J;
-      // (0) the observation row of the NEXT step, so that its latency hides behind this step's arithmetic
-      rows_load<PXL>(yq[(J + 1) & 1], P.y + (size_t)min(max(i + 1 - HW, 0), H - 1) * W, c0, W, i + 1 - HW >= 0 && i + 1 - HW < H);
+      // (0) the observation row of the step after next
+      rows_load<PXL>(yq[(J + kYD) & 3], P.y + (size_t)min(max(i + kYD - HW, 0), H - 1) * W, c0, W, i + kYD - HW >= 0 && i + kYD - HW < H);
       // (1) horizontal blur of x row i
       float hx[PXL];
       {
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
       {
         const bool rowok = r >= 0 && r < H;
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) R[k] = (rowok && c0 + (k & ~3) < W) ? A[sr][k] - yq[J & 1][k] : 0.f;
+        for (int k = 0; k < PXL; ++k) R[k] = (rowok && c0 + (k & ~3) < W) ? A[sr][k] - yq[J & 3][k] : 0.f;
       }
       // (4) horizontal adjoint of the residual row
       float hr[PXL];
