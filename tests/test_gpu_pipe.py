@@ -145,3 +145,19 @@ def test_pipe_me_tv_inner_prox_chained(la):
     la.set_step_variant("auto")
     assert rel(outs[("g", "auto")], outs[("g", "tile")]) < 1e-5
     assert rel(outs["auto"], outs["tile"]) < 5e-6
+
+
+@pytest.mark.parametrize("shape", [(40, 264), (33, 160), (64, 512)])
+def test_pipe_pure_tv_prox_k10(la, shape):
+    """prox_{gamma TV} alone (no data term, K = 10) on wide images: the KT = 0 instantiation, against the oracle."""
+    rng = np.random.default_rng(8)
+    x = rng.uniform(0, 255, (3,) + shape)
+    la.set_step_variant("auto")
+    tv = la.TV(shape, sigma=0.3, niter=10)
+    got = np.stack([tv.prox(x[i].ravel().copy(), 2.5).reshape(shape) for i in range(3)])
+    want = np.stack([O.tv_prox_fgp(x[i], 0.3 * 2.5, 10) for i in range(3)])
+    assert rel(got, want) < 2e-6, rel(got, want)
+    la.set_step_variant("tile")
+    ref = np.stack([tv.prox(x[i].ravel().copy(), 2.5).reshape(shape) for i in range(3)])
+    la.set_step_variant("auto")
+    assert rel(got, ref) < 2e-6
