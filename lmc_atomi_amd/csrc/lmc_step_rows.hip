@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   // Vector-memory loads return in order, so the load a step consumes must be older than the x rows still in flight for later steps:
   // the observation row is requested kYD steps ahead and first in its step (one step ahead and after the x prefetch, every step
   // waited for an HBM access issued one step earlier).
-  constexpr int kYD = 2;
+  constexpr int kYD = 1;   // 2 was measured: no gain, and the extra ring slots cost the registers the packed build needs
   static_for<0, kYD>([&](auto dd) {   // observation rows of the first kYD steps (residual rows i_first - HW + d, slot (J & 3))
     constexpr int d = decltype(dd)::value;
     const int r = i_first + d - HW;
