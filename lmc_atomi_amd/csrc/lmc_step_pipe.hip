@@ -442,11 +442,29 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
     float crr[2][PXL], xprev[PXL];
 #pragma unroll
     for (int k = 0; k < PXL; ++k) crr[0][k] = crr[1][k] = xprev[k] = 0.f;
+    // rows of the ME-TV term's prox image (A.extra), requested three ticks ahead of their use (slot tick & 3): a load issued at
+    // its point of use would expose an HBM access per tick
+    float exq[4][PXL];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < PXL; ++k) exq[u][k] = 0.f;
+    if (A.extra) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int r = u - D;
+        gload_row<PXL>(exq[u], A.extra + (size_t)chain * img + (size_t)min(max(r, 0), H - 1) * W, c0, W, r >= 0 && r < H);
+      }
+    }
     auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
       constexpr int U = decltype(uu)::value, P = U & 1;
       constexpr int NI = ((U - D) % 4 + 4) % 4;        // == o & 3  (t = 4m + U)
       const int o = t - D;
       if (CHAIN && A.tv_state_only) { PIPE_TICK_SYNC(); return; }     // this link only advances the dual state
+      if (A.extra) {
+        const int r3 = o + 3;
+        gload_row<PXL>(exq[(U + 3) & 3], A.extra + (size_t)chain * img + (size_t)min(max(r3, 0), H - 1) * W, c0, W, r3 >= 0 && r3 < H);
+      }
       float css[PXL], xo[PXL], gv[PXL], prox[PXL];
       prow_load<PXL>(crr[P], hin + (P ^ 1) * HSTR, lane);            // rr^K on row o (written last tick)
       prow_load<PXL>(css, hin + (P ^ 1) * HSTR + BW, lane);
@@ -500,10 +518,7 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
               const float4 v = *reinterpret_cast<const float4*>(A.noise + (size_t)chain * img + go + c0 + 4 * g);
               xi[0] = v.x; xi[1] = v.y; xi[2] = v.z; xi[3] = v.w;
             }
-            if (A.extra) {
-              const float4 v = *reinterpret_cast<const float4*>(A.extra + (size_t)chain * img + go + c0 + 4 * g);
-              ex[0] = v.x; ex[1] = v.y; ex[2] = v.z; ex[3] = v.w;
-            }
+            if (A.extra) { ex[0] = exq[U][4 * g]; ex[1] = exq[U][4 * g + 1]; ex[2] = exq[U][4 * g + 2]; ex[3] = exq[U][4 * g + 3]; }
             float ov[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
