@@ -267,8 +267,9 @@ float lmc_set_cg_tolerance(float tol);
  * 2 = streaming register pipeline (one wave group), 3 = the same pipeline split over two wave groups,
  * 4 = HBM-bound tiled kernel for closed-form priors, 5 = register-block kernel (stencil-free data term, prox local to
  * 8 x 8 blocks: Haar-l1 / l2 / l1 / none; H, W multiples of 8), 6 = barrier-free row streaming (separable blur + closed-form
- * prior, W <= 512, W % 4 == 0).  Returns the previous setting (>= 0) or a negative lmc_status.
- * Both variants compute the same update; the switch exists for A/B tests and profiles. */
+ * prior, W <= 512, W % 4 == 0), 7 = stage-parallel full-width TV pipeline (isotropic TV with 10, 20, ... 60 dual iterations, separable
+ * blur or no data term, 132 <= W <= 512: the default of the headline configuration).  Returns the previous setting (>= 0) or a
+ * negative lmc_status.  All variants compute the same update; the switch exists for A/B tests and profiles. */
 int lmc_set_step_variant(int32_t variant);
 
 #ifdef __cplusplus
