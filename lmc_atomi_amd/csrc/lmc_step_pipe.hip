@@ -189,9 +189,16 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
   // Issue arbitration on the shared SIMDs: the short, latency-bound waves everybody waits for at the barrier (L publishes the
   // ring row, C frees the hand-off slot) go first, the TV waves next, the Philox wave -- pure arithmetic, a quad row-group ahead
   // of its consumer -- last.  Measured: 2.04 -> 1.98 ms; the other way round (TV waves first) 2.37 ms.
-  if (wave == 0 || wave == NT + 1) __builtin_amdgcn_s_setprio(3);
-  else if (wave <= NT) __builtin_amdgcn_s_setprio(1);
-  else __builtin_amdgcn_s_setprio(0);
+#ifndef LMC_PRIO_L
+#define LMC_PRIO_L 3
+#define LMC_PRIO_C 3
+#define LMC_PRIO_T 1
+#define LMC_PRIO_N 0
+#endif
+  if (wave == 0) __builtin_amdgcn_s_setprio(LMC_PRIO_L);
+  else if (wave == NT + 1) __builtin_amdgcn_s_setprio(LMC_PRIO_C);
+  else if (wave <= NT) __builtin_amdgcn_s_setprio(LMC_PRIO_T);
+  else __builtin_amdgcn_s_setprio(LMC_PRIO_N);
   if (wave == 0) {
     // ---------------- L: loader + blur gradient -------------------------------------------------------------
     const float* __restrict__ uv = A.blur.h;   // centred taps: u[0..KT) then v[0..KT) at h[kMaxBlur..]
