@@ -146,14 +146,25 @@ __device__ __forceinline__ void pipe_stage_first(const v2f (&xa)[NP], v2f (&solb
   for (int i = 0; i < NP; ++i) solb[i] = xa[i];
 }
 
+// Row load with zero fill.  The load itself is unconditional (masked-off lanes read the start of the row, always a valid address:
+// callers pass a clamped row) and the mask is applied to the value: a predicated load costs an exec-mask branch per access and
+// splits the tick into basic blocks the scheduler cannot move loads across.
 template <int PXL>
 __device__ __forceinline__ void gload_row(float (&dst)[PXL], const float* __restrict__ row, int c0, int W, bool ok) {
 #pragma unroll
   for (int g = 0; g < PXL / 4; ++g) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok && c0 + 4 * g < W) v = *reinterpret_cast<const float4*>(row + c0 + 4 * g);
-    dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
+    const bool okg = ok && c0 + 4 * g < W;
+    const float4 v = *reinterpret_cast<const float4*>(row + (okg ? c0 + 4 * g : 0));
+    dst[4 * g] = okg ? v.x : 0.f; dst[4 * g + 1] = okg ? v.y : 0.f; dst[4 * g + 2] = okg ? v.z : 0.f; dst[4 * g + 3] = okg ? v.w : 0.f;
   }
+}
+
+// wave shifts with zero fill through bound_ctrl (no "old" register to initialise)
+__device__ __forceinline__ float dpp_left0(float v) {    // lane i <- v[i-1]; lane 0 <- 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_right0(float v) {   // lane i <- v[i+1]; lane 63 <- 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
 // KT = 0: no data term (pure prox, or t = 0).  CHAIN: the launch is one link of a chain of launches that together run more than K
@@ -268,11 +279,11 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
         float xi[PXL], e[PXL + 2 * HW];
         prow_load<PXL>(xi, ring_row(i), lane);
 #pragma unroll
-        for (int m = 0; m < HW; ++m) e[m] = dpp_from_left(xi[PXL - HW + m], 0.f);
+        for (int m = 0; m < HW; ++m) e[m] = dpp_left0(xi[PXL - HW + m]);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) e[HW + k] = xi[k];
 #pragma unroll
-        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_from_right(xi[m], 0.f);
+        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_right0(xi[m]);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
           float acc = uv[kMaxBlur] * e[k + 2 * HW];
@@ -308,11 +319,11 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
       {   // horizontal adjoint, then G[r - HW] = sum_a u[a] hR[r - 2HW + a]
         float e[PXL + 2 * HW], gout[PXL];
 #pragma unroll
-        for (int m = 0; m < HW; ++m) e[m] = dpp_from_left(R[PXL - HW + m], 0.f);
+        for (int m = 0; m < HW; ++m) e[m] = dpp_left0(R[PXL - HW + m]);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) e[HW + k] = R[k];
 #pragma unroll
-        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_from_right(R[m], 0.f);
+        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_right0(R[m]);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
           float hrn = uv[kMaxBlur] * e[k];
