@@ -126,6 +126,14 @@ __device__ __forceinline__ float dpp_from_right(float v, float edge) {  // lane 
                                                               __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
+// wave shifts with zero fill through bound_ctrl: no "old" register to initialise (one v_mov less per shift)
+__device__ __forceinline__ float dpp_left0(float v) {    // lane i <- v[i-1]; lane 0 <- 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_right0(float v) {   // lane i <- v[i+1]; lane 63 <- 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
 // ---- horizontal neighbours at DPP-row (16-lane) granularity -----------------------------------------
 // wave_shr / wave_shl DPP moves cost ~12 cycles per wave on gfx950 (measured, scripts/ubench/stage_mix.hip);
 // row_shr:1 / row_shl:1 run at the plain VALU rate.  So neighbours inside a 16-lane row come from row

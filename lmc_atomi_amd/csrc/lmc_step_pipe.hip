@@ -93,14 +93,14 @@ __device__ __forceinline__ void pipe_stage(const v2f (&xa)[NP], const v2f (&r1)[
                                            v2f (&solb)[NP], float gam, float cdown, float cstep, float cr_last, float beta,
                                            DualRow<NP>& out) {
   v2f sol[NP];
-  const float ssl0 = dpp_from_left(s1[NP - 1].y, 0.f);
+  const float ssl0 = dpp_left0(s1[NP - 1].y);
   const v2f ngam = pk_set(-gam), ncd = pk_set(-cdown), vb = pk_set(beta);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const v2f ssl = v2f{i == 0 ? ssl0 : s1[i - 1].y, s1[i].x};
     sol[i] = pk_fma(ngam, (r1[i] - in0.rr[i]) + (s1[i] - ssl), xa[i]);
   }
-  const float solr_last = dpp_from_right(solb[0].x, 0.f);
+  const float solr_last = dpp_right0(solb[0].x);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const v2f solr = v2f{solb[i].y, i == NP - 1 ? solr_last : solb[i + 1].x};
@@ -126,7 +126,7 @@ __device__ __forceinline__ void pipe_stage(const v2f (&xa)[NP], const v2f (&r1)[
 template <int NP>
 __device__ __forceinline__ void pipe_stage_first(const v2f (&xa)[NP], v2f (&solb)[NP], float cdown, float cstep, float cr_last, float beta,
                                                  DualRow<NP>& out) {
-  const float solr_last = dpp_from_right(solb[0].x, 0.f);
+  const float solr_last = dpp_right0(solb[0].x);
   const v2f ncd = pk_set(-cdown), vb = pk_set(beta);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
@@ -157,14 +157,6 @@ __device__ __forceinline__ void gload_row(float (&dst)[PXL], const float* __rest
     const float4 v = *reinterpret_cast<const float4*>(row + (okg ? c0 + 4 * g : 0));
     dst[4 * g] = okg ? v.x : 0.f; dst[4 * g + 1] = okg ? v.y : 0.f; dst[4 * g + 2] = okg ? v.z : 0.f; dst[4 * g + 3] = okg ? v.w : 0.f;
   }
-}
-
-// wave shifts with zero fill through bound_ctrl (no "old" register to initialise)
-__device__ __forceinline__ float dpp_left0(float v) {    // lane i <- v[i-1]; lane 0 <- 0
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float dpp_right0(float v) {   // lane i <- v[i+1]; lane 63 <- 0
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
 // KT = 0: no data term (pure prox, or t = 0).  CHAIN: the launch is one link of a chain of launches that together run more than K
@@ -494,7 +486,7 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
       prow_load<PXL>(css, hin + (P ^ 1) * HSTR + BW, lane);
       prow_load<PXL>(xo, ring_row(o), lane);
       prow_load<PXL>(gv, lds + L::o_g + (P ^ 1) * BW, lane);
-      const float ssl0 = dpp_from_left(css[PXL - 1], 0.f);
+      const float ssl0 = dpp_left0(css[PXL - 1]);
 #pragma unroll
       for (int j = 0; j < PXL; ++j) {
         const float ssl = j == 0 ? ssl0 : css[j - 1];
@@ -504,8 +496,8 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
         // rows o-1 (kept in registers: its ring slot is being overwritten by row t this very tick), o, o+1 (ring)
         float xp[PXL];
         prow_load<PXL>(xp, ring_row(o + 1), lane);
-        const float xm_r = dpp_from_right(xprev[0], 0.f), x0_l = dpp_from_left(xo[PXL - 1], 0.f), x0_r = dpp_from_right(xo[0], 0.f),
-                    xp_l = dpp_from_left(xp[PXL - 1], 0.f);
+        const float xm_r = dpp_right0(xprev[0]), x0_l = dpp_left0(xo[PXL - 1]), x0_r = dpp_right0(xo[0]),
+                    xp_l = dpp_left0(xp[PXL - 1]);
 #pragma unroll
         for (int j = 0; j < PXL; ++j) {
           const int col = c0 + j;
@@ -519,7 +511,7 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
       if (A.g_out && o >= 0 && o < H) {   // isotropic TV of the input image, row o: forward differences, zero across the last row / column
         float xq[PXL];
         prow_load<PXL>(xq, ring_row(o + 1), lane);
-        const float xr_last = dpp_from_right(xo[0], 0.f);
+        const float xr_last = dpp_right0(xo[0]);
         const bool down = o + 1 < H;
 #pragma unroll
         for (int j = 0; j < PXL; ++j) {

@@ -28,6 +28,8 @@ struct RowsGeom {
   static constexpr int PF = 8 - LAG < LMC_ROWS_PF ? 8 - LAG : LMC_ROWS_PF;   // x rows fetched ahead; PF + LAG <= 8 keeps row o's slot intact
 };
 
+// Row load with zero fill (predicated: here the value must stay untouched until its use several steps later -- a select applied at
+// load time would wait for the prefetch at once; measured 0.75 vs 0.65 ms).
 template <int PXL>
 __device__ __forceinline__ void rows_load(float (&dst)[PXL], const float* __restrict__ row, int c0, int W, bool rowok) {
 #pragma unroll
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   static_for<0, PF>([&](auto pp) {
     constexpr int p = decltype(pp)::value;
     const int i = i_first + p;
-    rows_load<PXL>(xr[(8 - LAG + p) & 7], xin + (size_t)max(i, 0) * W, c0, W, i >= 0 && i < H);
+    rows_load<PXL>(xr[(8 - LAG + p) & 7], xin + (size_t)min(max(i, 0), H - 1) * W, c0, W, i >= 0 && i < H);
   });
 
   // Vector-memory loads return in order, so the load a step consumes must be older than the x rows still in flight for later steps:
@@ -106,11 +108,11 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
       {
         float e[PXL + 2 * HW];
 #pragma unroll
-        for (int m = 0; m < HW; ++m) e[m] = dpp_from_left(xr[J][PXL - HW + m], 0.f);
+        for (int m = 0; m < HW; ++m) e[m] = dpp_left0(xr[J][PXL - HW + m]);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) e[HW + k] = xr[J][k];
 #pragma unroll
-        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_from_right(xr[J][m], 0.f);
+        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_right0(xr[J][m]);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
           float acc = uv[kMaxBlur] * e[k + 2 * HW];
@@ -140,11 +142,11 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
       {
         float e[PXL + 2 * HW];
 #pragma unroll
-        for (int m = 0; m < HW; ++m) e[m] = dpp_from_left(R[PXL - HW + m], 0.f);
+        for (int m = 0; m < HW; ++m) e[m] = dpp_left0(R[PXL - HW + m]);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) e[HW + k] = R[k];
 #pragma unroll
-        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_from_right(R[m], 0.f);
+        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_right0(R[m]);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
           float acc = uv[kMaxBlur] * e[k];
