@@ -159,6 +159,17 @@ __device__ __forceinline__ void gload_row(float (&dst)[PXL], const float* __rest
   }
 }
 
+// The same without the select: for values that are masked where they are USED (a select at load time makes the wave wait for
+// the prefetch at once).  Lanes past the row read its start.
+template <int PXL>
+__device__ __forceinline__ void gload_raw(float (&dst)[PXL], const float* __restrict__ row, int c0, int W) {
+#pragma unroll
+  for (int g = 0; g < PXL / 4; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(row + (c0 + 4 * g < W ? c0 + 4 * g : 0));
+    dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
+  }
+}
+
 // KT = 0: no data term (pure prox, or t = 0).  CHAIN: the launch is one link of a chain of launches that together run more than K
 // dual iterations: stage 1 starts from the dual state A.tv_in of the previous link ([C][4][H][W]: rr, ss, p, q; NULL = zeros), the last
 // stage's state goes to A.tv_out (NULL = not stored), and with A.tv_state_only the combine / store of x_out is skipped.
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
 #pragma unroll
       for (int k = 0; k < PXL; ++k) { hxw[a][k] = 0.f; hrw[a][k] = 0.f; }
 #pragma unroll
-    for (int u = 0; u < kXPF; ++u) gload_row<PXL>(xpre[u], xin + (size_t)min(u, H - 1) * W, c0, W, u < H);
+    for (int u = 0; u < kXPF; ++u) gload_raw<PXL>(xpre[u], xin + (size_t)min(u, H - 1) * W, c0, W);
     // Vector-memory loads return in order: waiting for a load also waits for every load issued before it.  So the loads a tick
     // consumes must be the OLDEST in flight: y rows are requested three ticks ahead and, inside a tick, before the x row that is only
     // needed four ticks later (with y one tick ahead and issued after x, every tick waited for a fresh HBM access: ~2000 cycles).
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
 #pragma unroll
       for (int u = 0; u < kYPF; ++u) {
         const int r = u + 1 - D + (KT - 1) - HW;
-        gload_row<PXL>(ypre[u], A.y + (size_t)min(max(r, 0), H - 1) * W, c0, W, r >= 0 && r < H);
+        gload_raw<PXL>(ypre[u], A.y + (size_t)min(max(r, 0), H - 1) * W, c0, W);
       }
     }
     // chained launch: the dual state rows for stage 1, fetched two ticks ahead (row t - E - 1 is published at tick t)
@@ -246,14 +257,14 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
       constexpr int U = decltype(uu)::value, P = U & 1;
       if constexpr (KT > 0) {   // observation row of the residual row kYPF ticks from now
         const int r3 = t + kYPF + 1 - D + (KT - 1) - HW;
-        gload_row<PXL>(ypre[(U + kYPF) & 3], A.y + (size_t)min(max(r3, 0), H - 1) * W, c0, W, r3 >= 0 && r3 < H);
+        gload_raw<PXL>(ypre[(U + kYPF) & 3], A.y + (size_t)min(max(r3, 0), H - 1) * W, c0, W);
       }
       {   // row t arrives: publish it in the ring (zeros below the image); fetch row t + 4
         float xv[PXL];
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) xv[k] = t < H ? xpre[U][k] : 0.f;
+        for (int k = 0; k < PXL; ++k) xv[k] = (t < H && c0 + (k & ~3) < W) ? xpre[U][k] : 0.f;
         prow_store<PXL>(ring_row(t), lane, xv);
-        gload_row<PXL>(xpre[U], xin + (size_t)min(t + kXPF, H - 1) * W, c0, W, t + kXPF < H);
+        gload_raw<PXL>(xpre[U], xin + (size_t)min(t + kXPF, H - 1) * W, c0, W);
       }
       if constexpr (CHAIN) {   // dual state row t - E - 1 of the previous link -> stage 1's hand-off slot P (read next tick)
         float* hb = lds + L::o_hand0 + P * 4 * BW;
@@ -469,7 +480,7 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int r = u - D;
-        gload_row<PXL>(exq[u], A.extra + (size_t)chain * img + (size_t)min(max(r, 0), H - 1) * W, c0, W, r >= 0 && r < H);
+        gload_raw<PXL>(exq[u], A.extra + (size_t)chain * img + (size_t)min(max(r, 0), H - 1) * W, c0, W);
       }
     }
     auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
@@ -479,7 +490,7 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
       if (CHAIN && A.tv_state_only) { PIPE_TICK_SYNC(); return; }     // this link only advances the dual state
       if (A.extra) {
         const int r3 = o + 3;
-        gload_row<PXL>(exq[(U + 3) & 3], A.extra + (size_t)chain * img + (size_t)min(max(r3, 0), H - 1) * W, c0, W, r3 >= 0 && r3 < H);
+        gload_raw<PXL>(exq[(U + 3) & 3], A.extra + (size_t)chain * img + (size_t)min(max(r3, 0), H - 1) * W, c0, W);
       }
       float css[PXL], xo[PXL], gv[PXL], prox[PXL];
       prow_load<PXL>(crr[P], hin + (P ^ 1) * HSTR, lane);            // rr^K on row o (written last tick)
