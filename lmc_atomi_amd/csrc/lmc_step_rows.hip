@@ -40,6 +40,17 @@ __device__ __forceinline__ void rows_load(float (&dst)[PXL], const float* __rest
   }
 }
 
+// Unconditional load without the zero fill, for values masked where they are used (lanes past the row read its start; callers pass
+// a clamped, valid row): no exec-mask branch, and nothing touches the value before its use, so the prefetch stays in flight.
+template <int PXL>
+__device__ __forceinline__ void rows_load_raw(float (&dst)[PXL], const float* __restrict__ row, int c0, int W) {
+#pragma unroll
+  for (int g = 0; g < PXL / 4; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(row + (c0 + 4 * g < W ? c0 + 4 * g : 0));
+    dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
+  }
+}
+
 template <int PXL, int KT, bool DOT = false>
 __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step_rows_kernel(const StepArgs P, const int band_rows, const int nbands) {
   using Gm = RowsGeom<PXL, KT>;
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   static_for<0, PF>([&](auto pp) {
     constexpr int p = decltype(pp)::value;
     const int i = i_first + p;
-    rows_load<PXL>(xr[(8 - LAG + p) & 7], xin + (size_t)min(max(i, 0), H - 1) * W, c0, W, i >= 0 && i < H);
+    rows_load_raw<PXL>(xr[(8 - LAG + p) & 7], xin + (size_t)min(max(i, 0), H - 1) * W, c0, W);
   });
 
   // Vector-memory loads return in order, so the load a step consumes must be older than the x rows still in flight for later steps:
@@ -91,7 +102,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   static_for<0, kYD>([&](auto dd) {   // observation rows of the first kYD steps (residual rows i_first - HW + d, slot (J & 3))
     constexpr int d = decltype(dd)::value;
     const int r = i_first + d - HW;
-    rows_load<PXL>(yq[(8 - LAG + d) & 3], P.y + (size_t)min(max(r, 0), H - 1) * W, c0, W, r >= 0 && r < H);
+    rows_load_raw<PXL>(yq[(8 - LAG + d) & 3], P.y + (size_t)min(max(r, 0), H - 1) * W, c0, W);
   });
 
   double dacc = 0.0;       // sum x_in * x_out over this wave's band (P.dot_out: the p.Ap of CG)
@@ -102,17 +113,20 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
     constexpr int J = decltype(jj)::value;
     const int i = base + J;
       // (0) the observation row of the step after next
-      rows_load<PXL>(yq[(J + kYD) & 3], P.y + (size_t)min(max(i + kYD - HW, 0), H - 1) * W, c0, W, i + kYD - HW >= 0 && i + kYD - HW < H);
+      rows_load_raw<PXL>(yq[(J + kYD) & 3], P.y + (size_t)min(max(i + kYD - HW, 0), H - 1) * W, c0, W);
       // (1) horizontal blur of x row i
       float hx[PXL];
       {
-        float e[PXL + 2 * HW];
+        float e[PXL + 2 * HW], xm[PXL];
+        const bool rowin = i >= 0 && i < H;           // the ring holds raw loads: rows / columns outside the image are zeros HERE
 #pragma unroll
-        for (int m = 0; m < HW; ++m) e[m] = dpp_left0(xr[J][PXL - HW + m]);
+        for (int k = 0; k < PXL; ++k) xm[k] = (rowin && c0 + (k & ~3) < W) ? xr[J][k] : 0.f;
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) e[HW + k] = xr[J][k];
+        for (int m = 0; m < HW; ++m) e[m] = dpp_left0(xm[PXL - HW + m]);
 #pragma unroll
-        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_right0(xr[J][m]);
+        for (int k = 0; k < PXL; ++k) e[HW + k] = xm[k];
+#pragma unroll
+        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_right0(xm[m]);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
           float acc = uv[kMaxBlur] * e[k + 2 * HW];
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
       // (7) fetch x row i + PF into the slot row i + PF - 8 has just left (its last use was step (6) above at the latest)
       {
         const int ip = i + PF;
-        rows_load<PXL>(xr[(J + PF) & 7], xin + (size_t)min(max(ip, 0), H - 1) * W, c0, W, ip >= 0 && ip < H);
+        rows_load_raw<PXL>(xr[(J + PF) & 7], xin + (size_t)min(max(ip, 0), H - 1) * W, c0, W);
       }
   };
   const int r1r = (r1 + 7) & ~7;
