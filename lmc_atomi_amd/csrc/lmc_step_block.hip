@@ -33,62 +33,17 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
   const float* __restrict__ src = P.x_in + (size_t)chain * img + o0;
   float* __restrict__ dst = P.x_out + (size_t)chain * img + o0;
 
-  float v[8][8], base[8][8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const float4 lo = *reinterpret_cast<const float4*>(src + (size_t)r * W);
-    const float4 hi = *reinterpret_cast<const float4*>(src + (size_t)r * W + 4);
-    v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = lo.z; v[r][3] = lo.w; v[r][4] = hi.x; v[r][5] = hi.y; v[r][6] = hi.z; v[r][7] = hi.w;
-  }
-  // base = a*x - t*grad f(x)
-  const float ts = P.t * P.sigma_f;
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    float yv[8], mv[8];
-    if (DATA != LMC_DATA_NONE) {
-      const float4 lo = *reinterpret_cast<const float4*>(P.y + o0 + (size_t)r * W);
-      const float4 hi = *reinterpret_cast<const float4*>(P.y + o0 + (size_t)r * W + 4);
-      yv[0] = lo.x; yv[1] = lo.y; yv[2] = lo.z; yv[3] = lo.w; yv[4] = hi.x; yv[5] = hi.y; yv[6] = hi.z; yv[7] = hi.w;
-    }
-    if (DATA == LMC_DATA_MASK) {
-      const float4 lo = *reinterpret_cast<const float4*>(P.mask + o0 + (size_t)r * W);
-      const float4 hi = *reinterpret_cast<const float4*>(P.mask + o0 + (size_t)r * W + 4);
-      mv[0] = lo.x; mv[1] = lo.y; mv[2] = lo.z; mv[3] = lo.w; mv[4] = hi.x; mv[5] = hi.y; mv[6] = hi.z; mv[7] = hi.w;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float x = v[r][j];
-      float g = 0.f;                                            // grad f / sigma_f
-      if (DATA == LMC_DATA_IDENTITY) g = x - yv[j];
-      else if (DATA == LMC_DATA_MASK) g = mv[j] * fmaf(mv[j], x, -yv[j]);
-      base[r][j] = fmaf(P.a, x, -ts * g);
-    }
-  }
-  // + s * xi
-  if (P.noise_mode == LMC_NOISE_PHILOX) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float n[4];
-        quad_normals(P.key0, P.key1, P.iteration, P.chain_offset + chain, (uint32_t)(by * 2 + q) * (uint32_t)W + (uint32_t)(bx * 8 + j), n);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) base[4 * q + k][j] = fmaf(P.s, n[k], base[4 * q + k][j]);
-      }
-  } else if (P.noise_mode == LMC_NOISE_INJECTED) {
-    const float* __restrict__ nz = P.noise + (size_t)chain * img + o0;
+  // Phase 1: the block in registers, prox in place (Haar: butterflies + soft threshold; l2 / l1 / none are pointwise and need no
+  // copy at all).  Phase 2 re-reads x row by row (L2 hits: the wave has just streamed these lines) instead of holding a second
+  // 64-register copy of the block: 128 VGPRs less, 3-4 waves per SIMD instead of 2.
+  float v[8][8];
+  if (PRIOR == LMC_PRIOR_HAAR_L1) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const float4 lo = *reinterpret_cast<const float4*>(nz + (size_t)r * W);
-      const float4 hi = *reinterpret_cast<const float4*>(nz + (size_t)r * W + 4);
-      base[r][0] = fmaf(P.s, lo.x, base[r][0]); base[r][1] = fmaf(P.s, lo.y, base[r][1]);
-      base[r][2] = fmaf(P.s, lo.z, base[r][2]); base[r][3] = fmaf(P.s, lo.w, base[r][3]);
-      base[r][4] = fmaf(P.s, hi.x, base[r][4]); base[r][5] = fmaf(P.s, hi.y, base[r][5]);
-      base[r][6] = fmaf(P.s, hi.z, base[r][6]); base[r][7] = fmaf(P.s, hi.w, base[r][7]);
+      const float4 lo = *reinterpret_cast<const float4*>(src + (size_t)r * W);
+      const float4 hi = *reinterpret_cast<const float4*>(src + (size_t)r * W + 4);
+      v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = lo.z; v[r][3] = lo.w; v[r][4] = hi.x; v[r][5] = hi.y; v[r][6] = hi.z; v[r][7] = hi.w;
     }
-  }
-  // v <- prox(x)
-  if (PRIOR == LMC_PRIOR_HAAR_L1) {
     const float thr = P.prior_p0;
 #pragma unroll
     for (int s = 1; s <= 4; s <<= 1)        // forward: (i, j) holds LL, (i, j+s) LH, (i+s, j) HL, (i+s, j+s) HH of the quad at stride s
@@ -113,18 +68,62 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
           v[i + s][j] = 0.5f * (ll + lh - hl - hh); v[i + s][j + s] = 0.5f * (ll - lh - hl + hh);
         }
   }
+  // Phase 2: out = a*x - t*grad f(x) + b*prox(x) + s*xi, four rows (one Philox quad row-group) at a time
+  const float ts = P.t * P.sigma_f;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    float o[8];
+  for (int q = 0; q < 2; ++q) {
+    float nz[8][4];
+    if (P.noise_mode == LMC_NOISE_PHILOX) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float px = v[r][j];
-      if (PRIOR == LMC_PRIOR_L2) px = px * P.prior_p0;
-      else if (PRIOR == LMC_PRIOR_L1) px = soft_thr_b(px, P.prior_p0);
-      o[j] = fmaf(P.b, px, base[r][j]);
+      for (int j = 0; j < 8; ++j) {
+        quad_normals(P.key0, P.key1, P.iteration, P.chain_offset + chain, (uint32_t)(by * 2 + q) * (uint32_t)W + (uint32_t)(bx * 8 + j), nz[j]);
+        if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two Philox calls in flight, not eight: their temporaries decide the occupancy
+      }
     }
-    *reinterpret_cast<float4*>(dst + (size_t)r * W) = make_float4(o[0], o[1], o[2], o[3]);
-    *reinterpret_cast<float4*>(dst + (size_t)r * W + 4) = make_float4(o[4], o[5], o[6], o[7]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = 4 * q + k;
+      float xr[8], yv[8], mv[8], xi[8];
+      {
+        const float4 lo = *reinterpret_cast<const float4*>(src + (size_t)r * W);
+        const float4 hi = *reinterpret_cast<const float4*>(src + (size_t)r * W + 4);
+        xr[0] = lo.x; xr[1] = lo.y; xr[2] = lo.z; xr[3] = lo.w; xr[4] = hi.x; xr[5] = hi.y; xr[6] = hi.z; xr[7] = hi.w;
+      }
+      if (DATA != LMC_DATA_NONE) {
+        const float4 lo = *reinterpret_cast<const float4*>(P.y + o0 + (size_t)r * W);
+        const float4 hi = *reinterpret_cast<const float4*>(P.y + o0 + (size_t)r * W + 4);
+        yv[0] = lo.x; yv[1] = lo.y; yv[2] = lo.z; yv[3] = lo.w; yv[4] = hi.x; yv[5] = hi.y; yv[6] = hi.z; yv[7] = hi.w;
+      }
+      if (DATA == LMC_DATA_MASK) {
+        const float4 lo = *reinterpret_cast<const float4*>(P.mask + o0 + (size_t)r * W);
+        const float4 hi = *reinterpret_cast<const float4*>(P.mask + o0 + (size_t)r * W + 4);
+        mv[0] = lo.x; mv[1] = lo.y; mv[2] = lo.z; mv[3] = lo.w; mv[4] = hi.x; mv[5] = hi.y; mv[6] = hi.z; mv[7] = hi.w;
+      }
+      if (P.noise_mode == LMC_NOISE_INJECTED) {
+        const float* __restrict__ nzp = P.noise + (size_t)chain * img + o0 + (size_t)r * W;
+        const float4 lo = *reinterpret_cast<const float4*>(nzp);
+        const float4 hi = *reinterpret_cast<const float4*>(nzp + 4);
+        xi[0] = lo.x; xi[1] = lo.y; xi[2] = lo.z; xi[3] = lo.w; xi[4] = hi.x; xi[5] = hi.y; xi[6] = hi.z; xi[7] = hi.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xi[j] = P.noise_mode == LMC_NOISE_PHILOX ? nz[j][k] : 0.f;
+      }
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = xr[j];
+        float g = 0.f;                                            // grad f / sigma_f
+        if (DATA == LMC_DATA_IDENTITY) g = x - yv[j];
+        else if (DATA == LMC_DATA_MASK) g = mv[j] * fmaf(mv[j], x, -yv[j]);
+        float px = x;
+        if (PRIOR == LMC_PRIOR_HAAR_L1) px = v[r][j];
+        else if (PRIOR == LMC_PRIOR_L2) px = x * P.prior_p0;
+        else if (PRIOR == LMC_PRIOR_L1) px = soft_thr_b(x, P.prior_p0);
+        o[j] = fmaf(P.b, px, fmaf(P.s, xi[j], fmaf(P.a, x, -ts * g)));
+      }
+      *reinterpret_cast<float4*>(dst + (size_t)r * W) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(dst + (size_t)r * W + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
   }
 }
 
