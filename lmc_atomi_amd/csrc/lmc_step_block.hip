@@ -37,12 +37,15 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
   // copy at all).  Phase 2 re-reads x row by row (L2 hits: the wave has just streamed these lines) instead of holding a second
   // 64-register copy of the block: 128 VGPRs less, 3-4 waves per SIMD instead of 2.
   float v[8][8];
+  __shared__ float4 xs[PRIOR == LMC_PRIOR_HAAR_L1 ? 16 * 256 : 1];    // the thread's own copy of x: [row*2 + half][thread], 64 KB
   if (PRIOR == LMC_PRIOR_HAAR_L1) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const float4 lo = *reinterpret_cast<const float4*>(src + (size_t)r * W);
       const float4 hi = *reinterpret_cast<const float4*>(src + (size_t)r * W + 4);
       v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = lo.z; v[r][3] = lo.w; v[r][4] = hi.x; v[r][5] = hi.y; v[r][6] = hi.z; v[r][7] = hi.w;
+      xs[(2 * r) * 256 + threadIdx.x] = lo;
+      xs[(2 * r + 1) * 256 + threadIdx.x] = hi;
     }
     const float thr = P.prior_p0;
 #pragma unroll
@@ -85,8 +88,8 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
       const int r = 4 * q + k;
       float xr[8], yv[8], mv[8], xi[8];
       {
-        const float4 lo = *reinterpret_cast<const float4*>(src + (size_t)r * W);
-        const float4 hi = *reinterpret_cast<const float4*>(src + (size_t)r * W + 4);
+        const float4 lo = PRIOR == LMC_PRIOR_HAAR_L1 ? xs[(2 * r) * 256 + threadIdx.x] : *reinterpret_cast<const float4*>(src + (size_t)r * W);
+        const float4 hi = PRIOR == LMC_PRIOR_HAAR_L1 ? xs[(2 * r + 1) * 256 + threadIdx.x] : *reinterpret_cast<const float4*>(src + (size_t)r * W + 4);
         xr[0] = lo.x; xr[1] = lo.y; xr[2] = lo.z; xr[3] = lo.w; xr[4] = hi.x; xr[5] = hi.y; xr[6] = hi.z; xr[7] = hi.w;
       }
       if (DATA != LMC_DATA_NONE) {
