@@ -18,7 +18,10 @@ namespace lmc {
 
 __device__ __forceinline__ float soft_thr_b(float v, float thr) { return copysignf(fmaxf(fabsf(v) - thr, 0.f), v); }
 
-template <int DATA, int PRIOR>
+// MC: the MC-TV term of L2_ncvx_tv, -lambda * A^T(A x / max(|A x|, gamma)) (algs.py:273-277), added to the gradient: a rolling window
+// of three 10-pixel rows (block columns -1 .. 8) around the output row -- the interior from the LDS copy, the halo from the
+// neighbouring blocks in memory (cache hits: those lines are being streamed by the neighbouring threads).
+template <int DATA, int PRIOR, bool MC = false>
 __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(const StepArgs P) {
   const int H = P.H, W = P.W;
   const int nbx = W >> 3;
@@ -73,6 +76,27 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
   }
   // Phase 2: out = a*x - t*grad f(x) + b*prox(x) + s*xi, four rows (one Philox quad row-group) at a time
   const float ts = P.t * P.sigma_f;
+  // MC-TV window: wr[k][m] = x(row, block column m - 1), rows r-1, r, r+1 in slots (r-1)%3 ... ; addresses are clamped into the image,
+  // the has_* flags of mc_tv_grad make the clamped values irrelevant
+  float wr[MC ? 3 : 1][MC ? 10 : 1];
+  const int gi0 = by * 8, gj0 = bx * 8;
+  const float* __restrict__ ximg = P.x_in + (size_t)chain * img;
+  auto load_wrow = [&](float (&d)[MC ? 10 : 1], int rr) {      // rr: block-local row -1 .. 8
+    if constexpr (MC) {
+      const int gi = min(max(gi0 + rr, 0), H - 1);
+      const float* row = ximg + (size_t)gi * W;
+      if (PRIOR == LMC_PRIOR_HAAR_L1 && rr >= 0 && rr < 8) {
+        const float4 lo = xs[(2 * rr) * 256 + threadIdx.x], hi = xs[(2 * rr + 1) * 256 + threadIdx.x];
+        d[1] = lo.x; d[2] = lo.y; d[3] = lo.z; d[4] = lo.w; d[5] = hi.x; d[6] = hi.y; d[7] = hi.z; d[8] = hi.w;
+      } else {
+        const float4 lo = *reinterpret_cast<const float4*>(row + gj0), hi = *reinterpret_cast<const float4*>(row + gj0 + 4);
+        d[1] = lo.x; d[2] = lo.y; d[3] = lo.z; d[4] = lo.w; d[5] = hi.x; d[6] = hi.y; d[7] = hi.z; d[8] = hi.w;
+      }
+      d[0] = row[max(gj0 - 1, 0)];
+      d[9] = row[min(gj0 + 8, W - 1)];
+    }
+  };
+  if constexpr (MC) { load_wrow(wr[0], -1); load_wrow(wr[1], 0); }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     float nz[8][4];
@@ -111,6 +135,7 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
 #pragma unroll
         for (int j = 0; j < 8; ++j) xi[j] = P.noise_mode == LMC_NOISE_PHILOX ? nz[j][k] : 0.f;
       }
+      if constexpr (MC) load_wrow(wr[(r + 2) % 3], r + 1);
       float o[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -123,6 +148,12 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
         else if (PRIOR == LMC_PRIOR_L2) px = x * P.prior_p0;
         else if (PRIOR == LMC_PRIOR_L1) px = soft_thr_b(x, P.prior_p0);
         o[j] = fmaf(P.b, px, fmaf(P.s, xi[j], fmaf(P.a, x, -ts * g)));
+        if constexpr (MC) {
+          const float (&up)[10] = wr[r % 3], (&cu)[10] = wr[(r + 1) % 3], (&dn)[10] = wr[(r + 2) % 3];
+          const int gi = gi0 + r, gj = gj0 + j;
+          o[j] = fmaf(P.t * P.ncvx_lambda, mc_tv_grad(up[j + 1], up[j + 2], cu[j], cu[j + 1], cu[j + 2], dn[j], dn[j + 1], gi > 0, gi + 1 < H,
+                                                      gj > 0, gj + 1 < W, P.ncvx_gamma), o[j]);
+        }
       }
       *reinterpret_cast<float4*>(dst + (size_t)r * W) = make_float4(o[0], o[1], o[2], o[3]);
       *reinterpret_cast<float4*>(dst + (size_t)r * W + 4) = make_float4(o[4], o[5], o[6], o[7]);
@@ -132,7 +163,9 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
 
 bool block_supported(const StepArgs& a) {
   if ((a.H & 7) || (a.W & 7) || a.H < 8 || a.W < 8) return false;
-  if (a.data_kind == LMC_DATA_BLUR || a.ncvx_kind != LMC_NCVX_NONE || a.extra || a.prox_ext) return false;
+  if (a.data_kind == LMC_DATA_BLUR || a.extra || a.prox_ext) return false;
+  if (a.ncvx_kind == LMC_NCVX_MC_TV && a.prior_kind != LMC_PRIOR_HAAR_L1) return false;   // fused for the C5 combination only
+  if (a.ncvx_kind != LMC_NCVX_NONE && a.ncvx_kind != LMC_NCVX_MC_TV) return false;
   if (a.prior_kind == LMC_PRIOR_TV_ISO || a.prior_kind == LMC_PRIOR_TV_ANISO) return false;
   if (a.tv_in || a.tv_out) return false;
   return true;
@@ -143,7 +176,10 @@ static void launch_block_data(const StepArgs& a, int nblk, hipStream_t st) {
   switch (a.prior_kind) {
     case LMC_PRIOR_L2: hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_L2>), dim3(nblk), dim3(256), 0, st, a); break;
     case LMC_PRIOR_L1: hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_L1>), dim3(nblk), dim3(256), 0, st, a); break;
-    case LMC_PRIOR_HAAR_L1: hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_HAAR_L1>), dim3(nblk), dim3(256), 0, st, a); break;
+    case LMC_PRIOR_HAAR_L1:
+      if (a.ncvx_kind == LMC_NCVX_MC_TV) hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_HAAR_L1, true>), dim3(nblk), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_HAAR_L1>), dim3(nblk), dim3(256), 0, st, a);
+      break;
     default: hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_NONE>), dim3(nblk), dim3(256), 0, st, a); break;
   }
 }
