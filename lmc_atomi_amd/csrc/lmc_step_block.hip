@@ -2,11 +2,12 @@
 // an 8 x 8 block -- 3-level Haar-l1 (BASELINE config "inpainting mask + l1-wavelet prox"), l2, l1 or none:
 //     out = a*x - t*grad f(x) + b*prox(x) + s*xi                                   (algs.py:569)
 //
-// One thread owns one 8 x 8 block of one chain in registers: 16 float4 loads of x (the 64 lanes of a wave cover 8 image
-// rows x 512 contiguous columns), the pointwise data gradient and the Philox noise of the block (16 quads) are folded
-// into `base`, the Haar butterflies + soft threshold run in place on the copy of x, one fma per pixel and 16 float4 stores.
-// No LDS, no barrier, no halo: HBM traffic is x read once + x' written once (8 B per pixel-step); y and the mask are shared
-// by all chains and come from L2.
+// One thread owns one 8 x 8 block of one chain: 16 float4 loads of x (the 64 lanes of a wave cover 8 image rows x 512
+// contiguous columns); with the Haar prior the block goes to registers (butterflies + soft threshold in place) and a copy to a
+// thread-private LDS slab; then, four rows (one Philox quad row-group) at a time, x comes back from the slab (or is simply read,
+// for the pointwise priors), the data gradient, prox and noise are combined and stored as float4s.  No barrier, no halo (one
+// pixel of halo from memory when the MC-TV term is fused): HBM traffic is x read once + x' written once (8 B per pixel-step);
+// y and the mask are shared by all chains and come from L2.
 #include "lmc_device.h"
 #include "lmc_launch.h"
 
