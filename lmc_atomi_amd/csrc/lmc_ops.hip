@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void moments4_kernel(const float* __restrict__
                                                        double* __restrict__ s1, double* __restrict__ s2) {
   const size_t p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int c0 = blockIdx.y * seg_len;
-  const int c1 = p < img ? min(C, c0 + seg_len) : c0;      // threads past the image keep zeros (they still reach the barrier)
+  const int c1 = p < img ? min(C, c0 + seg_len) : c0;      // threads past the image keep zeros (they still take part in the shuffles)
   double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
   const float* __restrict__ src = x + p;
   int c = c0;
@@ -217,18 +217,25 @@ __global__ __launch_bounds__(256) void moments4_kernel(const float* __restrict__
     a[0] += d0; a[1] += d1; a[2] += d2; a[3] += d3;
     b[0] = fma(d0, d0, b[0]); b[1] = fma(d1, d1, b[1]); b[2] = fma(d2, d2, b[2]); b[3] = fma(d3, d3, b[3]);
   }
-  // lane-contiguous atomics (a wave's 64 adds hit 512 contiguous bytes): transpose the 4-pixel groups through LDS
-  __shared__ double sh[2][4 * 256];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { sh[0][4 * threadIdx.x + k] = a[k]; sh[1][4 * threadIdx.x + k] = b[k]; }
-  __syncthreads();
-  const size_t pb = (size_t)blockIdx.x * blockDim.x * 4;
+  // lane-contiguous atomics (a wave's 64 adds hit 512 contiguous bytes): the 4-pixel groups are transposed inside the wave with
+  // ds_bpermute shuffles -- no LDS allocation, so the kernel can share a CU with the step kernel (whose LDS is full) when the two
+  // run concurrently on different streams.  Atomic k of lane l covers pixel 64*k + l of the wave's 256: component l & 3 of lane 16*k + l/4.
+  const int lane = threadIdx.x & 63;
+  const size_t pw = ((size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * 4;     // first pixel of this wave
+  const int sel = lane & 3;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const size_t q = pb + (size_t)k * 256 + threadIdx.x;
+    const int srcl = 16 * k + (lane >> 2);
+    double va = 0.0, vb = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {            // the value of component m travels from lane srcl; each lane keeps the one it needs
+      const double ta = __shfl(a[m], srcl, 64), tb = __shfl(b[m], srcl, 64);
+      if (sel == m) { va = ta; vb = tb; }
+    }
+    const size_t q = pw + (size_t)k * 64 + lane;
     if (q < img) {
-      unsafeAtomicAdd(&s1[q], sh[0][k * 256 + threadIdx.x]);
-      unsafeAtomicAdd(&s2[q], sh[1][k * 256 + threadIdx.x]);
+      unsafeAtomicAdd(&s1[q], va);
+      unsafeAtomicAdd(&s2[q], vb);
     }
   }
 }
