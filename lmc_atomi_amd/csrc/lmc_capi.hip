@@ -809,7 +809,6 @@ int lmc_mymala_create(const lmc_myula_config* cfg, lmc_sampler** out) {
   hipError_t e = hipMalloc(&s->mx, nbytes);
   if (e == hipSuccess) e = hipMalloc(&s->xp, nbytes);
   if (e == hipSuccess) e = hipMalloc(&s->mxp, nbytes);
-  if (e == hipSuccess && s->noise_mode == LMC_NOISE_PHILOX) e = hipMalloc(&s->xi, nbytes);
   if (e == hipSuccess) e = hipMalloc(&s->mala_d, sizeof(double) * 6 * (size_t)s->C);
   if (e == hipSuccess) e = hipMalloc(&s->flag, sizeof(int) * (size_t)s->C);
   if (e == hipSuccess) e = hipMalloc(&s->nacc, sizeof(unsigned long long) * (size_t)s->C);
@@ -845,9 +844,10 @@ static int mymala_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, 
   }
   for (int k = 0; k < n_iters; ++k) {
     const float* xi = noise_dev ? noise_dev + (size_t)k * per_iter : s->xi;
-    if (s->noise_mode == LMC_NOISE_PHILOX)
-      HIP_TRY(lmc::launch_noise(s->xi, C, s->prob.H, s->prob.W, s->base.key0, s->base.key1, (uint32_t)s->iteration, s->base.chain_offset, st));
-    if (s->noise_mode == LMC_NOISE_NONE) {   // deterministic proposal x' = m(x): d1 = 0
+    if (s->noise_mode == LMC_NOISE_PHILOX) {   // x' = m(x) + s xi with the Philox field drawn inside the proposal kernel, and ||x' - m(x)||^2
+      HIP_TRY(lmc::mala_propose_philox(s->mx, s->xp, C, s->prob.H, s->prob.W, s->base.s, s->base.key0, s->base.key1, (uint32_t)s->iteration,
+                                       s->base.chain_offset, d1, st));
+    } else if (s->noise_mode == LMC_NOISE_NONE) {   // deterministic proposal x' = m(x): d1 = 0
       HIP_TRY(hipMemcpyAsync(s->xp, s->mx, sizeof(float) * per_iter, hipMemcpyDeviceToDevice, st));
       HIP_TRY(hipMemsetAsync(d1, 0, sizeof(double) * C, st));
     } else {

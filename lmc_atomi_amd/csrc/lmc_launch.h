@@ -90,6 +90,8 @@ hipError_t ulpda_cg_solve(float* u, const float* rhs, float* r, float* p, float*
 namespace lmc {
 // Metropolis adjustment glue (lmc_mala.hip)
 hipError_t mala_propose(const float* mx, const float* xi, float* xp, int64_t C, size_t img, float s, double* d1, hipStream_t st);
+hipError_t mala_propose_philox(const float* mx, float* xp, int64_t C, int H, int W, float s, uint32_t key0, uint32_t key1,
+                               uint32_t iteration, uint32_t chain_offset, double* d1, hipStream_t st);
 hipError_t mala_accept(int C, double* U, const double* fp, const double* gp, const double* d1, const double* d2, float tau,
                        uint32_t key0, uint32_t key1, uint32_t iteration, uint32_t chain_offset, int* flag,
                        unsigned long long* nacc, double* log_alpha, hipStream_t st);

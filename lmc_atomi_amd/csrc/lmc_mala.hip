@@ -26,6 +26,49 @@ __global__ __launch_bounds__(256) void mala_propose_kernel(const float* __restri
   if (threadIdx.x == 0) unsafeAtomicAdd(&d1[c], t);
 }
 
+// The same with the Philox field drawn in place (no xi buffer, no separate noise pass): one thread = one quad (4 rows of a column),
+// the counter layout of every step kernel (ctr = (quad, iteration, global chain, stream tag), key = seed).
+__global__ __launch_bounds__(256) void mala_propose_philox_kernel(const float* __restrict__ mx, float* __restrict__ xp, int H, int W, float s,
+                                                                  uint32_t key0, uint32_t key1, uint32_t iteration, uint32_t chain_offset,
+                                                                  double* __restrict__ d1) {
+  __shared__ double scratch[4];
+  const size_t c = blockIdx.y;
+  const size_t img = (size_t)H * W;
+  const int nq = (H + 3) >> 2;
+  const size_t total = (size_t)nq * W;
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i / W), col = (int)(i - (size_t)q * W);
+    float n[4];
+    quad_normals(key0, key1, iteration, chain_offset + (uint32_t)c, (uint32_t)q * (uint32_t)W + (uint32_t)col, n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * q + j;
+      if (r < H) {
+        const size_t k = c * img + (size_t)r * W + col;
+        const float m = mx[k];
+        const float p = fmaf(s, n[j], m);
+        xp[k] = p;
+        const double d = (double)p - (double)m;
+        acc += d * d;
+      }
+    }
+  }
+  const double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) unsafeAtomicAdd(&d1[c], t);
+}
+
+hipError_t mala_propose_philox(const float* mx, float* xp, int64_t C, int H, int W, float s, uint32_t key0, uint32_t key1,
+                               uint32_t iteration, uint32_t chain_offset, double* d1, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(d1, 0, sizeof(double) * C, st);
+  if (e != hipSuccess) return e;
+  const size_t total = (size_t)((H + 3) / 4) * W;
+  int gx = (int)((total + 255) / 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(mala_propose_philox_kernel, dim3(gx, (unsigned)C), dim3(256), 0, st, mx, xp, H, W, s, key0, key1, iteration, chain_offset, d1);
+  return hipGetLastError();
+}
+
 hipError_t mala_propose(const float* mx, const float* xi, float* xp, int64_t C, size_t img, float s, double* d1, hipStream_t st) {
   hipError_t e = hipMemsetAsync(d1, 0, sizeof(double) * C, st);
   if (e != hipSuccess) return e;
