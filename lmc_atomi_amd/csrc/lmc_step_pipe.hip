@@ -576,7 +576,10 @@ static constexpr size_t pipe_lds_bytes() { return sizeof(float) * (size_t)PipeLd
 // Number of links a configuration needs (0: not covered): 10 dual iterations per launch; more (20, 30, ... 60) as a chain of
 // launches that hand the dual state (rr, ss, p, q) over in HBM -- exact, the same mechanism as the tile kernel's chunks.
 int pipe_links(const StepArgs& a) {
-  if (a.prior_kind != LMC_PRIOR_TV_ISO || a.tv.niter < 10 || a.tv.niter > kMaxTvIters || a.tv.niter % 10) return 0;
+  if (a.prior_kind != LMC_PRIOR_TV_ISO || a.tv.niter > kMaxTvIters) return 0;
+  // one launch: 2, 6, 8, 10 (measured at 512x512x1024: 0.99 / 1.60 / 1.79 / 1.85 ms vs 1.25 / 1.78 / 2.10 / 2.36 split; 4: 1.53 vs 1.42, left to split)
+  const bool single = a.tv.niter == 2 || a.tv.niter == 6 || a.tv.niter == 8 || a.tv.niter == 10;
+  if (!single && (a.tv.niter < 20 || a.tv.niter % 10)) return 0;                                                     // 20, 30, ... 60: chained
   if (a.prox_ext || a.tv_in || a.tv_out || a.tv_state_only) return 0;
   // 8 (4) pixels per lane above (up to) 256 columns; narrower than 129 columns half the lanes idle and the split kernel wins
   if (a.W > 512 || a.W <= 128 || (a.W & (a.W > 256 ? 7 : 3)) || a.H < 1) return 0;
@@ -587,22 +590,22 @@ int pipe_links(const StepArgs& a) {
     return 0;                                  // pointwise data terms: split kernel
   }
   if (a.data_kind == LMC_DATA_NONE && (a.ncvx_kind != LMC_NCVX_NONE || a.f_out)) return 0;
-  return a.tv.niter / 10;
+  return single ? 1 : a.tv.niter / 10;
 }
 
 bool pipe_supported(const StepArgs& a) { return pipe_links(a) == 1; }
 
-template <int PXL, int KT, bool CHAIN>
+template <int PXL, int KT, bool CHAIN, int K = 10>
 static hipError_t pipe_launch_one(const StepArgs& a, hipStream_t st) {
-  auto kern = myula_step_pipe_kernel<10, PXL, KT, CHAIN>;
-  constexpr size_t lb = pipe_lds_bytes<10, PXL, KT, CHAIN>();
+  auto kern = myula_step_pipe_kernel<K, PXL, KT, CHAIN>;
+  constexpr size_t lb = pipe_lds_bytes<K, PXL, KT, CHAIN>();
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.C), dim3(64 * (10 / 2 + 3)), lb, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.C), dim3(64 * (K / 2 + 3)), lb, st, a);
   return hipGetLastError();
 }
 
@@ -618,6 +621,19 @@ static hipError_t pipe_dispatch(const StepArgs& a, int KT, hipStream_t st) {
   return pipe_launch_one<4, 0, CHAIN>(a, st);
 }
 
+// fewer dual iterations (2, 4, 6, 8): the same kernel with fewer TV waves
+template <int K>
+static hipError_t pipe_dispatch_k(const StepArgs& a, int KT, hipStream_t st) {
+  if (a.W > 256) {
+    if (KT == 5) return pipe_launch_one<8, 5, false, K>(a, st);
+    if (KT == 7) return pipe_launch_one<8, 7, false, K>(a, st);
+    return pipe_launch_one<8, 0, false, K>(a, st);
+  }
+  if (KT == 5) return pipe_launch_one<4, 5, false, K>(a, st);
+  if (KT == 7) return pipe_launch_one<4, 7, false, K>(a, st);
+  return pipe_launch_one<4, 0, false, K>(a, st);
+}
+
 // state0 / state1: [C][4][H][W] ping-pong buffers for the dual state between links (needed when a.tv.niter > 10)
 hipError_t launch_step_pipe(StepArgs a, hipStream_t st, float* state0, float* state1) {
   const int links = pipe_links(a);
@@ -628,7 +644,14 @@ hipError_t launch_step_pipe(StepArgs a, hipStream_t st, float* state0, float* st
     KT = centred_blur_taps(a, uc, vc);
     for (int i = 0; i < kMaxBlur; ++i) { a.blur.h[i] = i < KT ? uc[i] : 0.f; a.blur.h[kMaxBlur + i] = i < KT ? vc[i] : 0.f; }
   }
-  if (links == 1) return pipe_dispatch<false>(a, KT, st);
+  if (links == 1) {
+    switch (a.tv.niter) {
+      case 2: return pipe_dispatch_k<2>(a, KT, st);
+      case 6: return pipe_dispatch_k<6>(a, KT, st);
+      case 8: return pipe_dispatch_k<8>(a, KT, st);
+      default: return pipe_dispatch<false>(a, KT, st);
+    }
+  }
   float* st_buf[2] = {state0, state1};
   for (int j = 0; j < links; ++j) {
     StepArgs b = a;

@@ -161,3 +161,33 @@ def test_pipe_pure_tv_prox_k10(la, shape):
     ref = np.stack([tv.prox(x[i].ravel().copy(), 2.5).reshape(shape) for i in range(3)])
     la.set_step_variant("auto")
     assert rel(got, ref) < 2e-6
+
+
+@pytest.mark.parametrize("K", [2, 6, 8])
+@pytest.mark.parametrize("shape", [(40, 512), (33, 160)])
+def test_pipe_kernel_fewer_dual_iterations(la, shape, K):
+    """2, 4, 6, 8 dual iterations: the same kernel with fewer TV waves, against the oracle step and the tiled kernel."""
+    sigma, tau_reg = 0.75, 0.3
+    gamma, tau = sigma ** 2, 0.2 * sigma ** 2
+    rng = np.random.default_rng(40 + K)
+    img, h, off, y = problem(shape, rng)
+    pf = la.L2(Op=la.Convolve2D(shape, h, offset=off), b=y, sigma=1 / sigma ** 2)
+    op = {"kind": "tv", "sigma": tau_reg, "niter": K, "t": gamma}
+    x0 = img[None] + rng.normal(0, 10, (2,) + shape)
+    noise = rng.standard_normal((2, 2) + shape)
+    outs = {}
+    for v in ("tile", "auto"):
+        la.set_step_variant(v)
+        smp = la.MYULASampler(pf, la.TV(shape, sigma=tau_reg, niter=K), shape, n_chains=2, tau=tau, gamma=gamma, noise="injected")
+        smp.set_state(x0)
+        x = x0.copy()
+        for it in range(2):
+            smp.step(1, noise=noise[it:it + 1])
+            x = O.myula_step(x, y, h, off, 1 / sigma ** 2, tau, gamma, op, noise[it])
+            assert rel(smp.get_state().cpu().numpy(), x) < 2e-6 * (it + 1)
+        if v == "auto":
+            assert smp.kernel_name == "myula_step_pipe_kernel"
+        outs[v] = smp.get_state().cpu().numpy()
+        smp.close()
+    la.set_step_variant("auto")
+    assert rel(outs["auto"], outs["tile"]) < 2e-6
