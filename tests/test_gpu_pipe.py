@@ -100,12 +100,12 @@ def test_pipe_kernel_with_me_tv_term_matches_tile(la):
     assert rel(outs["auto"], outs["tile"]) < 3e-6, rel(outs["auto"], outs["tile"])
 
 
-@pytest.mark.parametrize("shape,K", [((40, 264), 20), ((33, 160), 50), ((21, 512), 30)])
-def test_pipe_chained_launches_long_tv_prox(la, shape, K):
+@pytest.mark.parametrize("shape,K,k", [((40, 264), 20, 5), ((33, 160), 50, 5), ((21, 512), 30, 5), ((24, 512), 20, 7), ((19, 200), 20, 6)])
+def test_pipe_chained_launches_long_tv_prox(la, shape, K, k):
     """More than 10 dual iterations: a chain of launches handing the dual state (rr, ss, p, q) over in HBM -- the TV prox alone
     (no data term) against the oracle, and the full update (blur + TV(K) + noise) against the tiled kernel's exact chunks."""
     rng = np.random.default_rng(31)
-    img, h, off, y = problem(shape, rng)
+    img, h, off, y = problem(shape, rng, k)
     x = img[None] + rng.normal(0, 8, (2,) + shape)
     la.set_step_variant("auto")
     tv = la.TV(shape, sigma=0.3, niter=K)
