@@ -48,20 +48,36 @@ def synth_problem(H, W, sigma, seed=0):
 
 
 def cpu_baseline(H, W, h, y, sigma, tau_reg, niter_tv, chains=4, iters=20):
-    """The oracle (numpy restatement of the reference loop, float64, PCG64 noise, 1 thread) on a bounded
-    sample of the same workload.  Checker / baseline only -- never on the product path."""
+    """The oracle on a bounded sample of the same workload, timed on this host: the C restatement
+    (oracle/lmc_oracle_c.c, float64, OpenMP over chains, PCG64 noise from numpy) on up to 16 cores -- the GPU box's CPU
+    share for one GPU -- is the reported value; the numpy restatement (the one pinned by the reference's own outputs;
+    the two agree bit for bit, tests/test_oracle_c.py) and the C one on a single core are reported beside it.
+    Checker / baseline only -- never on the product path."""
     from oracle import lmc_oracle as O
+    from oracle import lmc_oracle_c as OC
+    OC.build()
     gamma, tau = sigma ** 2, 0.2 * sigma ** 2
     prior = {"kind": "tv", "sigma": tau_reg, "niter": niter_tv, "t": gamma}
-    rng = np.random.default_rng(0)
-    x = np.zeros((chains, H, W))
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        x = O.myula_step(x, y, h, (2, 2), 1 / sigma ** 2, tau, gamma, prior, rng.standard_normal(x.shape))
-    dt = time.perf_counter() - t0
-    return {"value": chains * iters / dt, "unit": "chain-it/s", "cores": 1, "kind": "port",
-            "sample": f"{chains} chains x {iters} iterations of the same {H}x{W} MYULA-TV(K={niter_tv}) workload, "
-                      f"oracle/lmc_oracle.py float64 numpy, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+
+    def run(step, n_chains, n_it, **kw):
+        rng = np.random.default_rng(0)
+        x = np.zeros((n_chains, H, W))
+        t0 = time.perf_counter()
+        for _ in range(n_it):
+            x = step(x, y, h, (2, 2), 1 / sigma ** 2, tau, gamma, prior, rng.standard_normal(x.shape), **kw)
+        dt = time.perf_counter() - t0
+        return n_chains * n_it / dt, dt
+
+    v_np, t_np = run(O.myula_step, chains, max(1, iters // 2))
+    v_c1, t_c1 = run(OC.myula_step, chains, iters, threads=1)
+    T = max(1, min(16, os.cpu_count() or 1, OC.max_threads()))
+    mc, mi = 4 * T, 2 * iters
+    v_mt, t_mt = run(OC.myula_step, mc, mi, threads=T)
+    return {"value": v_mt, "unit": "chain-it/s", "cores": T, "kind": "port",
+            "sample": f"{mc} chains x {mi} iterations of the same {H}x{W} MYULA-TV(K={niter_tv}) workload, "
+                      f"oracle/lmc_oracle_c.c float64 with {T} OpenMP threads, {t_mt:.1f} s on {T} of {os.cpu_count()} host cores",
+            "one_core": {"c": v_c1, "numpy": v_np, "unit": "chain-it/s",
+                         "sample": f"{chains} chains x {iters} (C, {t_c1:.1f} s) / {max(1, iters // 2)} (numpy, {t_np:.1f} s) iterations"}}
 
 
 def main():
