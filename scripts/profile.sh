@@ -9,7 +9,8 @@ mkdir -p $out
 export TMPDIR=/tmp
 args="--steps 10 --warmup 2 --no-cpu-baseline $*"
 cd $root
-rocprofv3 --kernel-trace --stats -d $out/trace --output-format csv -- python3 bench.py $args > $out/bench_trace.json 2> $out/trace.log
+targs="--steps 60 --warmup 10 --no-cpu-baseline $*"   # long enough for clocks to settle: the average must agree with bench.py
+rocprofv3 --kernel-trace --stats -d $out/trace --output-format csv -- python3 bench.py $targs > $out/bench_trace.json 2> $out/trace.log
 for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
             "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT" \
             "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_COUNT"; do
