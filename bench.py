@@ -116,8 +116,12 @@ def main():
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # LMC_BENCH_DIST=1 forces the RCCL path (process group, barrier, moment all-reduce, max-over-ranks) at world size 1:
+    # the rehearsal of the N > 1 code on a one-GPU box
+    use_dist = world > 1 or os.environ.get("LMC_BENCH_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import lmc_atomi_amd as la
@@ -156,7 +160,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -168,13 +172,13 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     smp.step(args.steps)
-    if world > 1 and not args.no_moments:
+    if use_dist and not args.no_moments:
         from lmc_atomi_amd.sharding import allreduce_moments
         s1, s2, cnt = smp.moments()
         s1, s2, cnt = allreduce_moments(s1, s2, cnt)         # RCCL over xGMI: posterior mean/var accumulators
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -238,7 +242,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(H, W, h, y, sigma, tau_reg, args.tv_iters, args.cpu_chains, args.cpu_iters)
         print(json.dumps(out))
     smp.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
