@@ -142,6 +142,12 @@ int lmc_energies(const lmc_problem* prob, const float* x_dev, int64_t n_img,
 /* out = prox_{thr * ||W_detail . ||_1}(x): 3-level orthonormal Haar, soft threshold of the detail coefficients.  H, W % 8 == 0. */
 int lmc_haar_l1_prox(const float* x_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W, float thr, void* stream);
 
+/* Chain probes for convergence diagnostics across chains (split R-hat / effective sample size; SURVEY 8(f).3 -- absent in the
+ * reference, whose only diagnostics are the per-iterate scalars of prox_lmc_deconv.py:128-133): every image is reduced to a
+ * ph x pw grid of block means, out[i][a][b] = mean of x_i over rows [a*H/ph, (a+1)*H/ph) x columns [b*W/pw, (b+1)*W/pw)
+ * (integer division).  1 <= ph <= H, 1 <= pw <= W, W <= 8192.  out_dev: n_img*ph*pw floats. */
+int lmc_chain_probes(const float* x_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W, int32_t ph, int32_t pw, void* stream);
+
 /* Per-pixel projection of the stacked field y[2][H][W] onto the l2 ball (isotropic != 0) or the
  * box (isotropic == 0) of radius `radius`: L21.proxdual / L1.proxdual (algs.py:436,448). */
 int lmc_dual_project(const float* y_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W,

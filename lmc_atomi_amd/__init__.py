@@ -10,11 +10,13 @@ from .algs import (MYULAResult, MYULASampler, MYMALASampler, MoreauYosidaUnadjus
                    UnadjustedLangevinPrimalDual, mean_var_from_moments,
                    set_step_variant, set_cg_tolerance)
 
-from . import metrics
+from . import diagnostics, metrics
+from .diagnostics import ChainTrace, chain_probes, ess, split_rhat
 from .metrics import MetricsCallback, mean_squared_error, peak_signal_noise_ratio, signal_noise_ratio
-from .sharding import allreduce_moments, chain_shard, posterior_mean_var, sharded_myula
+from .sharding import allgather_chains, allreduce_moments, chain_shard, posterior_mean_var, sharded_myula
 
 __all__ = [
+    "diagnostics", "ChainTrace", "chain_probes", "ess", "split_rhat", "allgather_chains",
     "metrics", "MetricsCallback", "mean_squared_error", "peak_signal_noise_ratio", "signal_noise_ratio",
     "allreduce_moments", "chain_shard", "posterior_mean_var", "sharded_myula",
     "LMCError", "Convolve2D", "Diagonal", "Gradient", "Identity", "LinearOperator",

@@ -103,6 +103,7 @@ _SIGNATURES = {
     "lmc_mymala_create": (C.c_int, [C.POINTER(lmc_myula_config), C.POINTER(_P)]),
     "lmc_sampler_get_acceptance": (C.c_int, [_P, _P, _P, _P]),
     "lmc_set_cg_tolerance": (C.c_float, [C.c_float]),
+    "lmc_chain_probes": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "lmc_haar_l1_prox": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, _P]),
     "lmc_dual_project": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P]),
     "lmc_prox_elementwise": (C.c_int, [C.c_int32, _P, _P, C.c_int64, _F, C.c_int32, _P]),

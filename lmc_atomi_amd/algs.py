@@ -325,14 +325,15 @@ def mean_var_from_moments(s1, s2, count):
 class MYULAResult:
     """Return value of the many-chain form of :func:`MoreauYosidaUnadjustedLangevin`."""
 
-    def __init__(self, state, mean, var, count, energy_f, energy_g, elapsed):
+    def __init__(self, state, mean, var, count, energy_f, energy_g, elapsed, diagnostics=None, trace=None):
         self.state, self.mean, self.var, self.count = state, mean, var, count
         self.energy_f, self.energy_g, self.elapsed = energy_f, energy_g, elapsed
+        self.diagnostics, self.trace = diagnostics, trace      # split R-hat / ESS across chains (diagnostics.py), [T, C, Q] trace
 
 
 def MoreauYosidaUnadjustedLangevin(proxf, proxg, x0, tau=None, gamma=.1, epsg=1., niter=10, seed=0,
                                    callback=None, show=False, *, n_chains=None, dims=None, rng="philox",
-                                   chain_offset=0, burn_in=0, thin=1, device=None):
+                                   chain_offset=0, burn_in=0, thin=1, device=None, diagnostics=None):
     r"""Moreau--Yosida Unadjusted Langevin algorithm (MYULA) -- drop-in for algs.py:477-587.
 
     .. math::
@@ -347,7 +348,9 @@ def MoreauYosidaUnadjustedLangevin(proxf, proxg, x0, tau=None, gamma=.1, epsg=1.
 
     Many-chain form (``n_chains=C``): runs C chains from ``x0`` (one image or ``[C,H,W]``), keeps
     no iterates, returns a :class:`MYULAResult` (final states, posterior mean / variance over
-    chains and kept iterations, per-chain energies).
+    chains and kept iterations, per-chain energies).  ``diagnostics=(ph, pw)`` (or ``True`` = (8, 8)) additionally records,
+    at every kept iteration, a ph x pw grid of block means and the energies of every chain and returns split R-hat and
+    effective sample size across chains in ``result.diagnostics`` (:mod:`lmc_atomi_amd.diagnostics`).
     """
     if dims is None:
         dims = getattr(proxf, "dims", None) or getattr(proxg, "dims", None)
@@ -397,11 +400,21 @@ def MoreauYosidaUnadjustedLangevin(proxf, proxg, x0, tau=None, gamma=.1, epsg=1.
                 print('---------------------------------------------------------\n')
             return samples
         # many chains: no iterates kept
+        tracer = None
+        if diagnostics:
+            from .diagnostics import ChainTrace
+            tracer = ChainTrace(smp, (8, 8) if diagnostics is True else diagnostics)
+        next_rec = burn_in + 1                       # iteration counts after which the sampler has accumulated moments
         done = 0
         while done < niter:
             chunk = niter - done if (callback is None and not show) else 1
+            if tracer is not None and next_rec > done:
+                chunk = min(chunk, next_rec - done)
             smp.step(chunk)
             done += chunk
+            if tracer is not None and done == next_rec:
+                tracer.record()
+                next_rec += thin
             if callback is not None:
                 callback(smp.get_state())
             if show and (done <= 10 or niter - done < 10 or (done - 1) % max(niter // 10, 1) == 0):
@@ -414,7 +427,9 @@ def MoreauYosidaUnadjustedLangevin(proxf, proxg, x0, tau=None, gamma=.1, epsg=1.
         state = smp.get_state()
         torch.cuda.current_stream().synchronize()
         mean, var = mean_var_from_moments(s1, s2, max(cnt, 1))
-        return MYULAResult(state, mean, var, cnt, f, g, time.time() - tstart)
+        diag = tracer.summary() if tracer is not None and len(tracer) else None
+        return MYULAResult(state, mean, var, cnt, f, g, time.time() - tstart, diagnostics=diag,
+                           trace=tracer.trace() if diag is not None else None)
     finally:
         smp.close()
 

@@ -567,6 +567,14 @@ int lmc_haar_l1_prox(const float* x_dev, float* out_dev, int64_t n_img, int32_t 
   return LMC_OK;
 }
 
+int lmc_chain_probes(const float* x_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W, int32_t ph, int32_t pw, void* stream) {
+  if (!x_dev || !out_dev || n_img < 1 || H < 1 || W < 1) return fail(LMC_E_INVALID, "bad arguments");
+  if (ph < 1 || pw < 1 || ph > H || pw > W) return fail(LMC_E_INVALID, "probe grid %dx%d does not fit a %dx%d image", ph, pw, H, W);
+  if (W > 8192) return fail(LMC_E_UNSUPPORTED, "W <= 8192 (got %d)", W);
+  HIP_TRY(lmc::launch_chain_probes(x_dev, out_dev, n_img, H, W, ph, pw, S(stream)));
+  return LMC_OK;
+}
+
 int lmc_dual_project(const float* y_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W, float radius,
                      int32_t isotropic, void* stream) {
   if (!y_dev || !out_dev) return fail(LMC_E_INVALID, "NULL pointer");

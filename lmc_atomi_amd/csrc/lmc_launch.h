@@ -29,6 +29,7 @@ hipError_t launch_dual_project(const float* y, float* out, int64_t n_img, int H,
                                hipStream_t st);
 hipError_t launch_eprox(int kind, const float* x, float* out, int64_t n, float p0, float p1, hipStream_t st);
 hipError_t launch_haar_prox(const float* x, float* out, int64_t n_img, int H, int W, float thr, hipStream_t st);
+hipError_t launch_chain_probes(const float* x, float* out, int64_t n_img, int H, int W, int ph, int pw, hipStream_t st);
 hipError_t launch_haar_value(const float* x, int64_t n_img, int H, int W, float sigma, double* val, hipStream_t st);
 hipError_t launch_mc_tv_add(const float* x, float* out, int64_t n_img, int H, int W, float coef, float gamma, hipStream_t st);
 hipError_t launch_moments(const float* x, int C, int H, int W, double* s1, double* s2, hipStream_t st);

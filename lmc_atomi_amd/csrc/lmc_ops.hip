@@ -574,4 +574,36 @@ hipError_t launch_noise(float* out, int C, int H, int W, uint32_t key0, uint32_t
   return hipGetLastError();
 }
 
+// ---- chain probes: every image reduced to a ph x pw grid of block means (convergence diagnostics across chains) ----
+// One workgroup per (probe row, image): column sums of the band in double (coalesced row reads), then one thread per probe.
+__global__ void __launch_bounds__(256) chain_probe_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int ph, int pw) {
+  extern __shared__ double probe_colsum[];
+  const int a = blockIdx.x;
+  const size_t img = blockIdx.y;
+  const int r0 = (int)((int64_t)a * H / ph), r1 = (int)((int64_t)(a + 1) * H / ph);
+  const float* xi = x + img * (size_t)H * W;
+  for (int col = threadIdx.x; col < W; col += 256) {
+    double s = 0.0;
+    for (int r = r0; r < r1; ++r) s += (double)xi[(size_t)r * W + col];
+    probe_colsum[col] = s;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < pw; b += 256) {
+    const int c0 = (int)((int64_t)b * W / pw), c1 = (int)((int64_t)(b + 1) * W / pw);
+    double s = 0.0;
+    for (int c = c0; c < c1; ++c) s += probe_colsum[c];
+    out[(img * ph + a) * pw + b] = (float)(s / ((double)(r1 - r0) * (double)(c1 - c0)));
+  }
+}
+
+// out[i, a, b] = mean of x_i over rows [a H/ph, (a+1) H/ph) x columns [b W/pw, (b+1) W/pw)   (1 <= ph <= H, 1 <= pw <= W)
+hipError_t launch_chain_probes(const float* x, float* out, int64_t n_img, int H, int W, int ph, int pw, hipStream_t st) {
+  for (int64_t z0 = 0; z0 < n_img; z0 += 65535) {
+    const int nz = (int)((n_img - z0) < 65535 ? (n_img - z0) : 65535);
+    hipLaunchKernelGGL(chain_probe_kernel, dim3(ph, nz), dim3(256), (size_t)W * sizeof(double), st, x + z0 * (size_t)H * W,
+                       out + z0 * (size_t)ph * pw, H, W, ph, pw);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace lmc

@@ -31,7 +31,7 @@ def synthetic_image(ny=512, nx=512, seed=1234):
 
 
 def prox_lmc_deconv(gamma_mc=15., gamma_me=15., sigma=0.75, tau=0.3, N=1000, niter_l2=50, niter_tv=10, image=None,
-                    alg='ULPDA', seed=0, n_chains=None, burn_in=0, thin=1, models=None, verbose=True):
+                    alg='ULPDA', seed=0, n_chains=None, burn_in=0, thin=1, models=None, verbose=True, diagnostics=None):
     """Posterior means of the nine models M1..M9 (prox_lmc_deconv.py:447-703) by ULPDA or MYULA on the GPU.
 
     ``n_chains=None`` runs the reference's single chain (every iterate kept on the host, mean over iterates,
@@ -75,7 +75,8 @@ def prox_lmc_deconv(gamma_mc=15., gamma_me=15., sigma=0.75, tau=0.3, N=1000, nit
         elif alg == 'MYULA':                                        # :465-473
             res = MoreauYosidaUnadjustedLangevin(f, TV(dims=(ny, nx), sigma=tau, niter=niter_tv), tau=tau_myula,
                                                  gamma=gamma_myula, x0=x0, niter=N, seed=seed, n_chains=n_chains,
-                                                 burn_in=burn_in, thin=thin)
+                                                 burn_in=burn_in, thin=thin,
+                                                 **({"diagnostics": diagnostics} if (diagnostics and n_chains) else {}))
         elif alg == 'MYMALA':                                       # Metropolis-adjusted MYULA (generalises prox_lmc.py:134-158)
             res = MoreauYosidaMetropolisAdjustedLangevin(f, TV(dims=(ny, nx), sigma=tau, niter=niter_tv), tau=tau_myula,
                                                          gamma=gamma_myula, x0=x0, niter=N, seed=seed, n_chains=n_chains or 1,
@@ -88,6 +89,13 @@ def prox_lmc_deconv(gamma_mc=15., gamma_me=15., sigma=0.75, tau=0.3, N=1000, nit
                      "psnr": float(peak_signal_noise_ratio(img, mean, dims=(ny, nx))),
                      "mse": float(mean_squared_error(img, mean, dims=(ny, nx))),
                      "seconds": time.time() - t0}
+        diag = getattr(res, "diagnostics", None)
+        if diag is not None:                                        # split R-hat / ESS across chains (diagnostics.py)
+            out[name].update(rhat_max=diag["rhat_max"], ess_min=diag["ess_min"], rhat=diag["rhat"].cpu().numpy(),
+                             ess=diag["ess"].cpu().numpy())
+            if verbose:
+                print(f"    {name}: {diag['n_chains']} chains x {diag['n_kept']} kept iterations, block means + energies: "
+                      f"max split R-hat {diag['rhat_max']:.3f}, min ESS {diag['ess_min']:.0f}")
         if verbose:
             print(f"{alg} posterior mean {name} ({k}x{k} blur, {kind}): SNR {out[name]['snr']:.3f} dB  "
                   f"PSNR {out[name]['psnr']:.3f} dB  MSE {out[name]['mse']:.4f}  [{out[name]['seconds']:.1f} s]")
@@ -110,6 +118,7 @@ def main(argv=None):
     ap.add_argument("--n_chains", type=int, default=None)
     ap.add_argument("--burn_in", type=int, default=0)
     ap.add_argument("--thin", type=int, default=1)
+    ap.add_argument("--diagnostics", action="store_true", help="MYULA with --n_chains: split R-hat / ESS across chains (8x8 block means + energies)")
     ap.add_argument("--size", type=int, default=512, help="side of the synthetic test image")
     ap.add_argument("--image", default=None, help=".npy file with a 2-D grayscale image in [0, 255]")
     ap.add_argument("--models", default=None, help="comma-separated subset of M1..M9")
@@ -117,7 +126,7 @@ def main(argv=None):
     a = ap.parse_args(argv)
     img = np.load(a.image) if a.image else synthetic_image(a.size, a.size)
     res = prox_lmc_deconv(a.gamma_mc, a.gamma_me, a.sigma, a.tau, a.N, a.niter_l2, a.niter_tv, img, a.alg, a.seed, a.n_chains,
-                          a.burn_in, a.thin, a.models.split(",") if a.models else None)
+                          a.burn_in, a.thin, a.models.split(",") if a.models else None, diagnostics=a.diagnostics)
     if a.out:
         flat = {}
         for k, v in res.items():

@@ -37,6 +37,27 @@ def allreduce_moments(s1: torch.Tensor, s2: torch.Tensor, count: int, group=None
     return packed[:n].reshape(s1.shape), packed[n:2 * n].reshape(s2.shape), int(round(float(packed[2 * n])))
 
 
+def allgather_chains(t: torch.Tensor, dim: int = 1, group=None):
+    """Concatenate per-rank tensors along their chain dimension in rank order (= global chain order under
+    :func:`chain_shard`); ranks may own different numbers of chains.  Used for the diagnostics trace ``[T, C_rank, Q]``
+    (a few MB), so that R-hat / ESS run over the chains of the whole job.  Two small collectives (counts, padded payload)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    world = dist.get_world_size(group)
+    t = t.movedim(dim, 0).contiguous()
+    cnt = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    cmax = max(counts)
+    pad = torch.zeros((cmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0).movedim(0, dim)
+
+
 def posterior_mean_var(s1, s2, count):
     mean = s1 / count
     return mean, s2 / count - mean * mean

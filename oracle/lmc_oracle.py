@@ -753,6 +753,84 @@ def myula_batched(x0, y, h, offset, sigma_f, tau, gamma, prior, niter, noise_fn,
 
 
 # ----------------------------------------------------------------------------------
+# Convergence diagnostics across chains (ABSENT in the reference, whose diagnostics are the per-iterate
+# scalars of prox_lmc_deconv.py:128-133) -- build-specified, restated from the published definitions:
+# split R-hat of Gelman et al. (BDA3, sec. 11.4) and the multi-chain effective sample size with Geyer's initial
+# monotone sequence truncation as described in the Stan reference manual ("Effective sample size").  Plain loops on purpose:
+# the device-side version (lmc_atomi_amd/diagnostics.py) is vectorised, this is its independent check.
+# ----------------------------------------------------------------------------------
+
+def chain_probes(x, ph, pw):
+    """Block means of every image over a ph x pw grid: rows [a*H//ph, (a+1)*H//ph) x columns [b*W//pw, (b+1)*W//pw)."""
+    x = np.asarray(x, dtype=np.float64)
+    H, W = x.shape[-2:]
+    xf = x.reshape(-1, H, W)
+    out = np.empty((xf.shape[0], ph, pw))
+    for a in range(ph):
+        r0, r1 = a * H // ph, (a + 1) * H // ph
+        for b in range(pw):
+            c0, c1 = b * W // pw, (b + 1) * W // pw
+            out[:, a, b] = xf[:, r0:r1, c0:c1].mean(axis=(1, 2))
+    return out.reshape(xf.shape[0], ph * pw)
+
+
+def split_rhat(tr):
+    """Split R-hat of one scalar quantity; ``tr[T, M]`` = T kept iterations of M chains."""
+    tr = np.asarray(tr, dtype=np.float64)
+    T, M = tr.shape
+    n = T // 2
+    if n < 2:
+        return float("nan")
+    halves = [tr[:n, j] for j in range(M)] + [tr[T - n:, j] for j in range(M)]
+    means = np.array([h.mean() for h in halves])
+    variances = np.array([h.var(ddof=1) for h in halves])
+    m = len(halves)
+    B = n * means.var(ddof=1)
+    Wn = variances.mean()
+    var_plus = (n - 1) / n * Wn + B / n
+    return float(np.sqrt(var_plus / Wn))
+
+
+def ess_geyer(tr, max_lag=None):
+    """Effective sample size of one scalar quantity over all chains; ``tr[T, M]``."""
+    tr = np.asarray(tr, dtype=np.float64)
+    T, M = tr.shape
+    if T < 4:
+        return float("nan")
+    L = T - 1 if max_lag is None else min(T - 1, int(max_lag))
+    mean_m = tr.mean(axis=0)
+    acov = np.empty((L + 1, M))
+    for m in range(M):
+        d = tr[:, m] - mean_m[m]
+        for t in range(L + 1):
+            acov[t, m] = np.dot(d[:T - t], d[t:]) / T
+    chain_var = acov[0] * T / (T - 1)
+    Wn = chain_var.mean()
+    var_plus = Wn * (T - 1) / T
+    if M > 1:
+        var_plus += mean_m.var(ddof=1)
+    rho = np.empty(L + 1)
+    for t in range(L + 1):
+        rho[t] = 1.0 - (Wn - acov[t].mean()) / var_plus
+    rho[0] = 1.0
+    tau = -1.0
+    prev = None
+    t = 0
+    while t + 1 <= L:
+        P = rho[t] + rho[t + 1]
+        if P <= 0:
+            break
+        if prev is not None and P > prev:
+            P = prev
+        tau += 2.0 * P
+        prev = P
+        t += 2
+    N = T * M
+    tau = max(tau, 1.0 / math.log10(N))
+    return float(N / tau)
+
+
+# ----------------------------------------------------------------------------------
 # Counter-based RNG (device noise): Philox4x32-10 + Box-Muller, float32
 # ----------------------------------------------------------------------------------
 
