@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.
 BYTES_PER_PIXEL_STEP = 8       # algorithmic: one fp32 read of x_k + one fp32 write of x_{k+1}
 
 
-def synth_problem(H, W, sigma, seed=0):
+def synth_problem(H, W, sigma, seed=0, blur="box"):
     """Piecewise-constant + ramp ground truth in [0,255] from default_rng(1234); y = H u + N(0, sigma^2)
     with noise from default_rng(seed) (mirrors prox_lmc_deconv.py:53-59).  Host-side setup, not timed."""
     rng = np.random.default_rng(1234)
@@ -40,7 +40,10 @@ def synth_problem(H, W, sigma, seed=0):
         u[i0:i1, j0:j1] = rng.uniform(20, 235)
     u += np.linspace(0, 20, W)[None, :]
     u = np.clip(u, 0, 255)
-    h = np.ones((5, 5)) / 25.0
+    h = np.ones((5, 5)) / 25.0            # the reference's uniform box (prox_lmc_deconv.py:55-59)
+    if blur == "gaussian":                 # BASELINE.json says "Gaussian-deblur": 5x5, s = 1; same kernels, runtime taps
+        t = np.exp(-0.5 * (np.arange(5) - 2.0) ** 2)
+        h = np.outer(t, t) / np.sum(np.outer(t, t))
     # blur with scipy (setup only): zero-padded 'same' convolution, centred 5x5
     import scipy.signal
     y = scipy.signal.convolve2d(u, h, mode="same") + np.random.default_rng(seed).normal(0, sigma, (H, W))
@@ -95,6 +98,7 @@ def main():
     ap.add_argument("--cg-iters", type=int, default=50, help="ULPDA: inner CG iterations of the implicit data step")
     ap.add_argument("--no-moments", action="store_true")
     ap.add_argument("--data", default="blur", choices=["blur", "identity", "mask"], help="data term (experiments)")
+    ap.add_argument("--blur", default="box", choices=["box", "gaussian"], help="5x5 blur: the reference's uniform box or a Gaussian (s=1)")
     ap.add_argument("--ncvx", default="none", choices=["none", "mc", "me"],
                     help="add the L2_ncvx_tv Moreau-difference term (lamda=0.3, gamma=15; SURVEY 8(d) C5)")
     ap.add_argument("--ncvx-iters", type=int, default=None, help="inner TV-prox iterations of the ME-TV term (default: --tv-iters; the reference uses niter_l2 = 50)")
@@ -134,7 +138,7 @@ def main():
     C = args.chains
     sigma, tau_reg = 0.75, 0.3                       # prox_lmc_deconv.py:40 defaults
     gamma, tau = sigma ** 2, 0.2 * sigma ** 2        # prox_lmc_deconv.py:92-94
-    u, h, y = synth_problem(H, W, sigma)
+    u, h, y = synth_problem(H, W, sigma, blur=args.blur)
     if args.data == "blur":
         pf = la.L2(Op=la.Convolve2D((H, W), h, offset=(2, 2)), b=y, sigma=1 / sigma ** 2)
     elif args.data == "mask":                        # inpainting: 60 % of the pixels observed
@@ -217,7 +221,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{H}x{W} MYULA " + {"blur": f"deblur (5x5 uniform box blur, sigma={sigma})", "mask": "inpainting (60 % mask)",
+                "workload": f"{H}x{W} MYULA " + {"blur": f"deblur (5x5 {'uniform box' if args.blur == 'box' else 'Gaussian s=1'} blur, sigma={sigma})", "mask": "inpainting (60 % mask)",
                                                    "identity": "denoise"}[args.data] + f" + {prior_desc}" + ({"none": "", "mc": " - MC-TV term (lamda=0.3, gamma=15)", "me": f" - ME-TV term (lamda=0.3, gamma=15, {args.ncvx_iters or args.tv_iters} inner its)"}[args.ncvx]) + ", "
                             f"{C} chains/GPU x {world} GPU, Philox noise, x0=0, "
                             + ("no moments" if args.no_moments else f"posterior moments every {args.thin} it"),

@@ -61,6 +61,44 @@ def test_pipe_kernel_matches_oracle_step(la, shape, k):
     la.set_step_variant("auto")
 
 
+def _gauss(k, s=1.0):
+    t = np.exp(-0.5 * ((np.arange(k) - k // 2) / s) ** 2)
+    return np.outer(t, t) / np.sum(np.outer(t, t))
+
+
+@pytest.mark.parametrize("name,h,off,expect_pipe", [
+    ("gaussian5", _gauss(5), (2, 2), True),                                  # BASELINE's "Gaussian-deblur": separable, symmetric
+    ("gaussian7", _gauss(7, 1.5), (3, 3), True),
+    ("asymmetric5", np.outer([1.0, 2.0, 4.0, 3.0, 0.5], [0.2, 1.0, 3.0, 0.7, 0.1]) / 66.0, (2, 2), True),   # conv vs corr flips
+    ("asymmetric_offcentre", np.outer([1.0, 2.0, 4.0], [3.0, 1.0, 0.5, 0.25]) / 33.25, (0, 3), True),
+    ("non_separable", np.array([[0.0, 1, 0], [1, 4, 1], [0, 1, 2]]) / 10.0, (1, 1), False),                  # rank 2: general kernels
+])
+def test_non_uniform_blur_kernels(la, name, h, off, expect_pipe):
+    """Runtime blur taps: Gaussian, asymmetric separable (catches a convolution / correlation mix-up of H and H^T) and a
+    non-separable kernel, which the pipe kernel must refuse and another kernel must get right."""
+    sigma, tau_reg = 0.75, 0.3
+    gamma, tau = sigma ** 2, 0.2 * sigma ** 2
+    rng = np.random.default_rng(77)
+    shape, C, nit = (37, 264), 2, 3
+    img = problem(shape, rng)[0]
+    y = O.blur(img, h, off) + rng.normal(0, sigma, shape)
+    pf = la.L2(Op=la.Convolve2D(shape, h, offset=off), b=y, sigma=1 / sigma ** 2)
+    op = {"kind": "tv", "sigma": tau_reg, "niter": 10, "t": gamma}
+    x0 = img[None] + rng.normal(0, 10, (C,) + shape)
+    noise = rng.standard_normal((nit, C) + shape)
+    la.set_step_variant("auto")
+    smp = la.MYULASampler(pf, la.TV(shape, sigma=tau_reg, niter=10), shape, n_chains=C, tau=tau, gamma=gamma, noise="injected")
+    smp.set_state(x0)
+    x = x0.copy()
+    for it in range(nit):
+        smp.step(1, noise=noise[it:it + 1])
+        x = O.myula_step(x, y, h, off, 1 / sigma ** 2, tau, gamma, op, noise[it])
+        got = smp.get_state().cpu().numpy()
+        assert rel(got, x) < 2e-6 * (it + 1), (name, it, rel(got, x))
+    assert (smp.kernel_name == "myula_step_pipe_kernel") == expect_pipe, (name, smp.kernel_name)
+    smp.close()
+
+
 def test_pipe_kernel_philox_matches_split(la):
     rng = np.random.default_rng(4)
     for shape, C in [((128, 512), 5), ((64, 384), 3)]:
