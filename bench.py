@@ -103,6 +103,7 @@ def main():
                     help="add the L2_ncvx_tv Moreau-difference term (lamda=0.3, gamma=15; SURVEY 8(d) C5)")
     ap.add_argument("--ncvx-iters", type=int, default=None, help="inner TV-prox iterations of the ME-TV term (default: --tv-iters; the reference uses niter_l2 = 50)")
     ap.add_argument("--noise", default="philox", choices=["philox", "none"], help="noise source (experiments)")
+    ap.add_argument("--tau-scale", type=float, default=1.0, help="multiplies the step size tau = 0.2 sigma^2 (MYMALA acceptance experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chains", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=20)
@@ -137,7 +138,7 @@ def main():
         W = args.width
     C = args.chains
     sigma, tau_reg = 0.75, 0.3                       # prox_lmc_deconv.py:40 defaults
-    gamma, tau = sigma ** 2, 0.2 * sigma ** 2        # prox_lmc_deconv.py:92-94
+    gamma, tau = sigma ** 2, 0.2 * sigma ** 2 * args.tau_scale        # prox_lmc_deconv.py:92-94
     u, h, y = synth_problem(H, W, sigma, blur=args.blur)
     if args.data == "blur":
         pf = la.L2(Op=la.Convolve2D((H, W), h, offset=(2, 2)), b=y, sigma=1 / sigma ** 2)
@@ -242,6 +243,9 @@ def main():
                 "algorithmic_bytes_per_launch": BYTES_PER_PIXEL_STEP * H * W * C,
             },
         }
+        if args.alg == "mymala":
+            out["config"]["acceptance_rate_mean"] = float(smp.acceptance_rate().mean())
+            out["config"]["tau_scale"] = args.tau_scale
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W, h, y, sigma, tau_reg, args.tv_iters, args.cpu_chains, args.cpu_iters)
         print(json.dumps(out))
