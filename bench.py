@@ -172,7 +172,8 @@ def main():
     smp.step(args.warmup)
     if not args.no_moments:
         smp.reset_moments()
-    if args.alg == "myula":
+    timed_launches = args.alg == "myula" and os.environ.get("LMC_BENCH_NO_TIMING") != "1"   # experiments: cost of the event records
+    if timed_launches:
         smp.enable_timing(True)
     sync_all()
     t0 = time.perf_counter()
@@ -187,7 +188,7 @@ def main():
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
-    if args.alg == "myula":
+    if timed_launches:
         kern_ms, launches = smp.last_step_timing()
     else:                        # ULPDA is a sequence of launches per iteration: quote the whole iteration
         kern_ms, launches = elapsed * 1e3, args.steps
