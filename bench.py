@@ -86,8 +86,8 @@ def cpu_baseline(H, W, h, y, sigma, tau_reg, niter_tv, chains=4, iters=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--width", type=int, default=0, help="image width if not square (experiments)")
     ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
@@ -171,6 +171,9 @@ def main():
 
     smp.step(args.warmup)
     if not args.no_moments:
+        if use_dist:                                 # warm the collective too (communicator set-up, buffers of this size)
+            from lmc_atomi_amd.sharding import allreduce_moments
+            allreduce_moments(*smp.moments())
         smp.reset_moments()
     timed_launches = args.alg == "myula" and os.environ.get("LMC_BENCH_NO_TIMING") != "1"   # experiments: cost of the event records
     if timed_launches:
