@@ -211,7 +211,10 @@ int lmc_sampler_get_acceptance(lmc_sampler* s, uint64_t* accepted_dev, double* l
 int lmc_sampler_set_state(lmc_sampler* s, const float* x_dev, void* stream);
 int lmc_sampler_get_state(lmc_sampler* s, float* x_dev, void* stream);
 /* Run n_iters iterations of algs.py:564-570 on every chain.  noise_dev is
- * [n_iters][n_chains][H][W] when noise_mode == LMC_NOISE_INJECTED, else NULL. */
+ * [n_iters][n_chains][H][W] when noise_mode == LMC_NOISE_INJECTED, else NULL.
+ * All work is enqueued on `stream`.  (Environment LMC_MOMENTS_OVERLAP=1 moves the posterior-moment reductions of all but the last
+ * iteration of a call to an internal side stream that runs under the following step kernel; the call still returns with everything
+ * it enqueued ordered before whatever the caller enqueues on `stream` next.) */
 int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, void* stream);
 /* iteration counter (number of completed iterations since creation / last set_iteration) */
 int64_t lmc_sampler_iteration(const lmc_sampler* s);

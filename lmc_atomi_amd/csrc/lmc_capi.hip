@@ -389,6 +389,11 @@ struct lmc_sampler {
   int* flag = nullptr;
   unsigned long long* nacc = nullptr;
   bool mala_fresh = false;               // mx / U match x[cur]
+  // moment reductions on a side stream, overlapping the next step kernel (HBM-bound reduction under a VALU-bound step kernel)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_step = nullptr;              // "the step that wrote x[cur] is done" (recorded on the caller's stream)
+  hipEvent_t ev_mom[2] = {nullptr, nullptr}; // "the reduction that reads x[i] is done" (recorded on the side stream)
+  bool mom_pending[2] = {false, false};
   std::vector<hipEvent_t> ev;   // pairs (begin, end) around each step-kernel launch of the last step() call
   bool timing = false;
   bool timed = false;
@@ -668,6 +673,9 @@ void lmc_sampler_destroy(lmc_sampler* s) {
   if (s->s1) (void)hipFree(s->s1);
   if (s->s2) (void)hipFree(s->s2);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+  if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
+  if (s->ev_step) (void)hipEventDestroy(s->ev_step);
+  for (hipEvent_t e : s->ev_mom) if (e) (void)hipEventDestroy(e);
   delete s;
 }
 
@@ -773,6 +781,19 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
       s->ev.push_back(e);
     }
   }
+  // LMC_MOMENTS_OVERLAP=1: run the moment reductions on a side stream under the following step kernel
+  static const bool want_overlap = [] { const char* e = getenv("LMC_MOMENTS_OVERLAP"); return e && atoi(e) != 0; }();
+  static const int bg_wgs = [] { const char* e = getenv("LMC_MOMENTS_BG_WGS"); return e ? atoi(e) : 128; }();   // 0: the full-speed kernel
+  bool overlap = want_overlap && s->moments && n_iters > 1;
+  if (overlap && !s->side) {
+    int prio_least = 0, prio_greatest = 0;     // lowest priority: the step kernel's workgroups go first
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    static const bool low_prio = [] { const char* e = getenv("LMC_MOMENTS_SIDE_PRIO"); return !e || atoi(e) != 0; }();
+    if (low_prio) HIP_TRY(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_least));
+    else HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_step, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&s->ev_mom[i], hipEventDisableTiming));
+  }
   for (int k = 0; k < n_iters; ++k) {
     lmc::StepArgs A = s->base;
     A.x_in = s->x[s->cur];
@@ -786,6 +807,10 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
       A.extra = s->extra;
       A.extra_coef = -s->prob.ncvx_lambda / s->prob.ncvx_gamma;
     }
+    if (s->mom_pending[s->cur ^ 1]) {   // this step overwrites x[cur ^ 1]: the reduction that still reads it must be done
+      HIP_TRY(hipStreamWaitEvent(st, s->ev_mom[s->cur ^ 1], 0));
+      s->mom_pending[s->cur ^ 1] = false;
+    }
     if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * k], st));
     const char* kname = nullptr;
     hipError_t e = launch_step(A, st, &kname, s->tvstate[0], s->tvstate[1], s->pxbuf);
@@ -795,12 +820,24 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * k + 1], st));
     s->cur ^= 1;
     if (s->moments && s->iteration >= s->burn_in && (s->iteration - s->burn_in) % s->thin == 0) {
-      HIP_TRY(lmc::launch_moments(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st));
+      if (overlap && k + 1 < n_iters) {   // reduce x[cur] on the side stream while the next step kernel runs
+        HIP_TRY(hipEventRecord(s->ev_step, st));
+        HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
+        HIP_TRY(lmc::launch_moments_bg(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, bg_wgs, s->side));
+        HIP_TRY(hipEventRecord(s->ev_mom[s->cur], s->side));
+        s->mom_pending[s->cur] = true;
+      } else {
+        for (int i = 0; i < 2; ++i)       // accumulators are shared: stay behind the side stream's reductions
+          if (s->mom_pending[i]) { HIP_TRY(hipStreamWaitEvent(st, s->ev_mom[i], 0)); s->mom_pending[i] = false; }
+        HIP_TRY(lmc::launch_moments(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st));
+      }
       s->count += (uint64_t)s->C;
     }
     ++s->iteration;
     ++s->last_launches;
   }
+  for (int i = 0; i < 2; ++i)             // everything this call enqueued is ordered before whatever the caller enqueues next
+    if (s->mom_pending[i]) { HIP_TRY(hipStreamWaitEvent(st, s->ev_mom[i], 0)); s->mom_pending[i] = false; }
   s->timed = s->timing;
   return LMC_OK;
 }

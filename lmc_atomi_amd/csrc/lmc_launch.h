@@ -33,6 +33,7 @@ hipError_t launch_chain_probes(const float* x, float* out, int64_t n_img, int H,
 hipError_t launch_haar_value(const float* x, int64_t n_img, int H, int W, float sigma, double* val, hipStream_t st);
 hipError_t launch_mc_tv_add(const float* x, float* out, int64_t n_img, int H, int W, float coef, float gamma, hipStream_t st);
 hipError_t launch_moments(const float* x, int C, int H, int W, double* s1, double* s2, hipStream_t st);
+hipError_t launch_moments_bg(const float* x, int C, int H, int W, double* s1, double* s2, int n_wg, hipStream_t st);
 hipError_t launch_energies(const float* x, int64_t n_img, const EnergyArgs& E, double* f_out, double* g_out,
                            hipStream_t st);
 hipError_t launch_noise(float* out, int C, int H, int W, uint32_t key0, uint32_t key1, uint32_t iteration,

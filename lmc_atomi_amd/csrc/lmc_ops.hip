@@ -240,6 +240,64 @@ __global__ __launch_bounds__(256) void moments4_kernel(const float* __restrict__
   }
 }
 
+// Background variant for the side stream: few workgroups, each walking several 1024-pixel groups, so that the reduction trickles
+// along under the (VALU-bound, load-latency-sensitive) step kernel instead of saturating HBM for 0.2 ms.
+__global__ __launch_bounds__(256) void moments4_bg_kernel(const float* __restrict__ x, int C, size_t img, int n_groups,
+                                                          double* __restrict__ s1, double* __restrict__ s2) {
+  const int lane = threadIdx.x & 63;
+  const int sel = lane & 3;
+  for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const size_t p = ((size_t)g * 256 + threadIdx.x) * 4;
+    const int c1 = p < img ? C : 0;
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    const float* __restrict__ src = x + p;
+    int c = 0;
+    for (; c + 4 <= c1; c += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(c + u) * img);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double d0 = v[u].x, d1 = v[u].y, d2 = v[u].z, d3 = v[u].w;
+        a[0] += d0; a[1] += d1; a[2] += d2; a[3] += d3;
+        b[0] = fma(d0, d0, b[0]); b[1] = fma(d1, d1, b[1]); b[2] = fma(d2, d2, b[2]); b[3] = fma(d3, d3, b[3]);
+      }
+    }
+    for (; c < c1; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * img);
+      const double d0 = v.x, d1 = v.y, d2 = v.z, d3 = v.w;
+      a[0] += d0; a[1] += d1; a[2] += d2; a[3] += d3;
+      b[0] = fma(d0, d0, b[0]); b[1] = fma(d1, d1, b[1]); b[2] = fma(d2, d2, b[2]); b[3] = fma(d3, d3, b[3]);
+    }
+    const size_t pw = ((size_t)g * 256 + (threadIdx.x & ~63)) * 4;     // first pixel of this wave (same transpose as moments4_kernel)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int srcl = 16 * k + (lane >> 2);
+      double va = 0.0, vb = 0.0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const double ta = __shfl(a[m], srcl, 64), tb = __shfl(b[m], srcl, 64);
+        if (sel == m) { va = ta; vb = tb; }
+      }
+      const size_t q = pw + (size_t)k * 64 + lane;
+      if (q < img) {
+        unsafeAtomicAdd(&s1[q], va);
+        unsafeAtomicAdd(&s2[q], vb);
+      }
+    }
+  }
+}
+
+// same result as launch_moments, paced: `n_wg` workgroups in total (H*W % 4 == 0 required, else falls back to launch_moments)
+hipError_t launch_moments_bg(const float* x, int C, int H, int W, double* s1, double* s2, int n_wg, hipStream_t st) {
+  const size_t img = (size_t)H * W;
+  if ((img & 3) || n_wg < 1) return launch_moments(x, C, H, W, s1, s2, st);
+  const int n_groups = (int)((img / 4 + 255) / 256);
+  if (n_wg > n_groups) n_wg = n_groups;
+  hipLaunchKernelGGL(moments4_bg_kernel, dim3(n_wg), dim3(256), 0, st, x, C, img, n_groups, s1, s2);
+  return hipGetLastError();
+}
+
 hipError_t launch_moments(const float* x, int C, int H, int W, double* s1, double* s2, hipStream_t st) {
   const size_t img = (size_t)H * W;
   if ((img & 3) == 0) {
