@@ -240,12 +240,13 @@ class ULPDASampler(MYULASampler):
 
 def UnadjustedLangevinPrimalDual(proxf, proxg, A, x0, tau, mu, y0=None, z=None, theta=1., niter=10, seed=0, gfirst=True,
                                  callback=None, callbacky=False, returny=False, show=False, *, n_chains=None, dims=None,
-                                 rng="philox", chain_offset=0, burn_in=0, thin=1, device=None):
+                                 rng="philox", chain_offset=0, burn_in=0, thin=1, device=None, diagnostics=None):
     r"""Unadjusted Langevin Primal-Dual algorithm (ULPDA) -- drop-in for algs.py:295-474.
 
     Reference form (``n_chains is None``): one chain, returns ``np.ndarray (niter, n)`` (and the duals ``(niter, 2n)`` with
     ``returny``), ``callback(x)`` / ``callback(x, y)`` every iteration, ``tau`` / ``mu`` scalars or per-iteration arrays
-    (algs.py:402-408).  ``rng='pcg64'`` injects the reference's noise stream.  Many-chain form: :class:`MYULAResult`.
+    (algs.py:402-408).  ``rng='pcg64'`` injects the reference's noise stream.  Many-chain form: :class:`MYULAResult`
+    (``diagnostics=(ph, pw)`` or ``True``: split R-hat / ESS across chains as in :func:`MoreauYosidaUnadjustedLangevin`).
     """
     if dims is None:
         dims = getattr(A, "dims", None) or getattr(proxf, "dims", None)
@@ -278,6 +279,10 @@ def UnadjustedLangevinPrimalDual(proxf, proxg, A, x0, tau, mu, y0=None, z=None, 
         host_rng = default_rng(seed) if rng == "pcg64" else None
         xs = np.empty((niter, n), dtype=np.float64) if not many else None
         ys = np.empty((niter, 2 * n), dtype=np.float64) if (returny and not many) else None
+        tracer = None
+        if diagnostics and many:
+            from .diagnostics import ChainTrace
+            tracer = ChainTrace(smp, (8, 8) if diagnostics is True else diagnostics)
         for it in range(niter):
             smp.set_steps(taus[it], mus[it])
             if host_rng is not None:
@@ -295,6 +300,8 @@ def UnadjustedLangevinPrimalDual(proxf, proxg, A, x0, tau, mu, y0=None, z=None, 
                     callback(xs[it], yk) if callbacky else callback(xs[it])
             elif callback is not None:
                 callback(smp.get_state(), smp.get_dual()) if callbacky else callback(smp.get_state())
+            if tracer is not None and it >= burn_in and (it - burn_in) % thin == 0:      # the iterations that enter the moments
+                tracer.record()
             if show and (it < 10 or niter - it < 10 or it % max(niter // 10, 1) == 0):
                 f, g = smp.energies()
                 x00 = float(smp.get_state().reshape(-1)[0])
@@ -310,7 +317,9 @@ def UnadjustedLangevinPrimalDual(proxf, proxg, A, x0, tau, mu, y0=None, z=None, 
         state = smp.get_state()
         torch.cuda.current_stream().synchronize()
         mean, var = mean_var_from_moments(s1, s2, max(cnt, 1))
-        return MYULAResult(state, mean, var, cnt, f, g, time.time() - tstart)
+        diag = tracer.summary() if tracer is not None and len(tracer) else None
+        return MYULAResult(state, mean, var, cnt, f, g, time.time() - tstart, diagnostics=diag,
+                           trace=tracer.trace() if diag is not None else None)
     finally:
         smp.close()
 

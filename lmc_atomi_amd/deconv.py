@@ -71,7 +71,8 @@ def prox_lmc_deconv(gamma_mc=15., gamma_me=15., sigma=0.75, tau=0.3, N=1000, nit
         t0 = time.time()
         if alg == 'ULPDA':                                          # :455-464
             res = UnadjustedLangevinPrimalDual(f, L21(ndim=2, sigma=tau), Gop, tau=tau0, mu=mu0, theta=1., x0=x0, gfirst=False,
-                                               niter=N, seed=seed, n_chains=n_chains, burn_in=burn_in, thin=thin)
+                                               niter=N, seed=seed, n_chains=n_chains, burn_in=burn_in, thin=thin,
+                                               **({"diagnostics": diagnostics} if (diagnostics and n_chains) else {}))
         elif alg == 'MYULA':                                        # :465-473
             res = MoreauYosidaUnadjustedLangevin(f, TV(dims=(ny, nx), sigma=tau, niter=niter_tv), tau=tau_myula,
                                                  gamma=gamma_myula, x0=x0, niter=N, seed=seed, n_chains=n_chains,
@@ -118,7 +119,7 @@ def main(argv=None):
     ap.add_argument("--n_chains", type=int, default=None)
     ap.add_argument("--burn_in", type=int, default=0)
     ap.add_argument("--thin", type=int, default=1)
-    ap.add_argument("--diagnostics", action="store_true", help="MYULA with --n_chains: split R-hat / ESS across chains (8x8 block means + energies)")
+    ap.add_argument("--diagnostics", action="store_true", help="with --n_chains (MYULA, ULPDA): split R-hat / ESS across chains (8x8 block means + energies)")
     ap.add_argument("--size", type=int, default=512, help="side of the synthetic test image")
     ap.add_argument("--image", default=None, help=".npy file with a 2-D grayscale image in [0, 255]")
     ap.add_argument("--models", default=None, help="comma-separated subset of M1..M9")

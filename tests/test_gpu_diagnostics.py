@@ -91,3 +91,16 @@ def test_chain_trace_as_callback_with_ulpda_sampler(la):
     s = tr.summary()
     assert tr.trace().shape == (6, C, 4) and s["rhat"].shape == (4,) and np.isfinite(s["rhat_max"])
     smp.close()
+
+
+def test_ulpda_dropin_reports_diagnostics(la):
+    H, W, C = 16, 24, 6
+    pf, _, sigma, y = _problem(la, H, W)
+    pf.niter = 20
+    res = la.UnadjustedLangevinPrimalDual(pf, la.L21(ndim=2, sigma=0.3), la.Gradient((H, W)), np.zeros(H * W), tau=0.95 * sigma ** 2, mu=1.0,
+                                          theta=1.0, niter=31, gfirst=False, seed=2, n_chains=C, dims=(H, W), burn_in=5, thin=3,
+                                          diagnostics=(2, 2))
+    d = res.diagnostics
+    assert res.trace.shape == (9, C, 6) and d["n_kept"] == 9 and res.count == 9 * C     # iterations 5, 8, ..., 29
+    assert d["rhat"].shape == (6,) and np.isfinite(d["rhat_max"]) and d["ess_min"] > 0
+    np.testing.assert_allclose(float(d["rhat"][0]), O.split_rhat(res.trace.cpu().numpy()[:, :, 0]), rtol=1e-9)
