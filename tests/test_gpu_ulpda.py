@@ -180,3 +180,27 @@ def test_cg_early_exit_matches_fixed_iterations(la):
     want = np.stack([ref.prox(v[i].ravel().copy(), 0.53) for i in range(3)])
     assert rel(outs[0.0], want) < 2e-6 and rel(outs[1e-6], want) < 5e-6
     assert rel(outs[("u", 1e-6)], outs[("u", 0.0)]) < 2e-5
+
+
+@pytest.mark.parametrize("k,off,shape", [(5, (2, 2), (32, 64)), (5, (2, 2), (48, 264)), (7, (3, 3), (40, 128)), (6, (3, 3), (36, 200)),
+                                          (5, (2, 2), (64, 512)), (3, (1, 1), (33, 12))])
+def test_l2_implicit_step_reaches_the_reference_tolerance(la, k, off, shape):
+    """Shapes the row-streaming kernel covers: the implicit step is the Chebyshev semi-iteration (one launch per iteration, iteration
+    count from the spectral bound).  The residual of the normal equations must meet the reference solver's stopping rule
+    |r| <= 1e-6 |b| (scipy lsqr btol, algs.py:250) up to fp32 rounding, cold and warm, and agree with a converged oracle solve."""
+    rng = np.random.default_rng(k + shape[1])
+    h = rng.uniform(0.5, 1.5, (k, 1)) * rng.uniform(0.5, 1.5, (1, k))
+    h /= h.sum()
+    b = rng.normal(100, 20, shape)
+    v = rng.normal(100, 20, (4,) + shape)
+    sig, tau = 1 / 0.75 ** 2, 0.53
+    l2 = la.L2(Op=la.Convolve2D(shape, h, offset=off), b=b.ravel(), sigma=sig, niter=50, warm=True)
+    ts = tau * sig
+    for rep in range(2):                       # second call: warm start from the first solution
+        u = np.asarray(l2.prox(v.reshape(4, -1), tau), dtype=np.float64).reshape((4,) + shape)
+        rhs = v + ts * O.blur_adjoint(b, h, off)[None]
+        res = rhs - (u + ts * O.blur_adjoint(O.blur(u, h, off), h, off))
+        for c in range(4):
+            assert np.linalg.norm(res[c]) <= 3e-6 * np.linalg.norm(rhs[c]), (rep, c, np.linalg.norm(res[c]) / np.linalg.norm(rhs[c]))
+    l2o = O.L2(Op=O.Convolve2D(shape, h, off), b=b.ravel(), sigma=sig, niter=300, warm=False)
+    assert rel(u[1].ravel(), l2o.prox(v[1].ravel(), tau)) < 5e-6
