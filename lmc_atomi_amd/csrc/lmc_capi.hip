@@ -301,8 +301,8 @@ float g_cg_tol = 1e-6f;   // relative residual at which the inner solver stops (
 // max|p_k| <= 2 c^k, c = (sqrt(kappa) - 1) / (sqrt(kappa) + 1): the iteration count for the reference's stopping rule |r| <= tol |b|
 // (scipy lsqr btol, algs.py:250) is known in advance -- no convergence test, no flags, no host synchronisation.
 // Returns hipErrorInvalidConfiguration when the row-streaming kernel does not cover the problem (caller falls back to CG).
-static hipError_t chebyshev_solve(const Problem& q, float ts, float* u, const float* rhs, float* tmp, int64_t C, int niter_cap, float tol,
-                                  const float* zero_y, hipStream_t st, int* n_done) {
+static hipError_t chebyshev_solve(const Problem& q, float ts, float* u, const float* rhs, float* tmp, double* scal, int64_t C, int niter_cap,
+                                  float tol, const float* zero_y, hipStream_t st) {
   lmc::StepArgs A;
   std::memset(&A, 0, sizeof A);
   A.H = q.H; A.W = q.W; A.C = (int)C;
@@ -326,7 +326,18 @@ static hipError_t chebyshev_solve(const Problem& q, float ts, float* u, const fl
   // A cap below what the tolerance needs makes the answer depend on the solver (a truncated iterate): leave that case to CG, whose
   // truncated iterates are the ones pinned by the tests; here every solve reaches the tolerance.
   if (k_need > niter_cap) return hipErrorInvalidConfiguration;
-  const int K = k_need;
+  static const int env_k = [] { const char* e = getenv("LMC_CHEB_K"); return e ? atoi(e) : 0; }();   // experiments: fixed count, no adaptation
+  int K = env_k > 0 ? env_k : k_need;
+  // A warm start begins with |r_0| << |rhs|: the first launch measures |r_0| and |rhs| on the fly, a one-block kernel turns them into the
+  // number of launches needed (even, <= the a-priori count), and the launches beyond it return at their first instruction.
+  const bool adaptive = env_k <= 0 && K > 2 && delta > 1e-12 * theta;
+  double* stat = scal;                                   // [2C]
+  int* count = reinterpret_cast<int*>(scal + 4 * C);     // the solver's flag word
+  if (adaptive) {
+    K = (K + 1) & ~1;
+    hipError_t e = hipMemsetAsync(scal, 0, sizeof(double) * (4 * C + 1), st);
+    if (e != hipSuccess) return e;
+  }
   float* cur = u;
   float* oth = tmp;
   double rho = delta > 0 ? delta / theta : 0.0;      // rho_0 = 1 / sigma_1
@@ -346,15 +357,24 @@ static hipError_t chebyshev_solve(const Problem& q, float ts, float* u, const fl
     A.b = (float)alpha;
     if (beta != 0.0) { A.noise_mode = LMC_NOISE_INJECTED; A.noise = oth; A.s = (float)(-beta); }   // oth holds u_{k-1} and receives u_{k+1}
     else { A.noise_mode = LMC_NOISE_NONE; A.noise = zero_y; A.s = 0.f; }
+    A.dot_out = nullptr; A.dot_mode = 0; A.run_count = nullptr; A.run_index = 0;
+    if (adaptive) {
+      if (k == 0) { A.dot_out = stat; A.dot_mode = 1; }
+      else { A.run_count = count; A.run_index = k; }
+    }
     hipError_t e = lmc::launch_step_rows(A, st);
     if (e != hipSuccess) return e;
+    if (adaptive && k == 0) {
+      const double sk = std::sqrt(lmax / lmin), c = (sk - 1.0) / (sk + 1.0);
+      e = lmc::cheb_count(C, stat, 1.0 / ((double)A.b * (double)A.b), (double)tol, 1.0 / std::log(1.0 / c), K, count, st);
+      if (e != hipSuccess) return e;
+    }
     float* t = cur; cur = oth; oth = t;
   }
   if (cur != u) {
     hipError_t e = hipMemcpyAsync(u, cur, sizeof(float) * (size_t)C * q.H * q.W, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return e;
   }
-  if (n_done) *n_done = K;
   return hipSuccess;
 }
 
@@ -364,7 +384,7 @@ int cg_solve_fused(const Problem& q, float ts, float* u, const float* rhs, float
   // LMC_IMPLICIT_SOLVER=cg keeps the conjugate-gradient path below (A/B runs); default: Chebyshev whenever a tolerance is set
   static const bool want_cheb = [] { const char* e = getenv("LMC_IMPLICIT_SOLVER"); return !(e && std::strcmp(e, "cg") == 0); }();
   if (want_cheb && g_cg_tol > 0.f) {
-    hipError_t e = chebyshev_solve(q, ts, u, rhs, r, C, niter, g_cg_tol, zero_y, st, nullptr);
+    hipError_t e = chebyshev_solve(q, ts, u, rhs, r, scal, C, niter, g_cg_tol, zero_y, st);
     if (e == hipSuccess) return LMC_OK;
     if (e != hipErrorInvalidConfiguration) HIP_TRY(e);
   }

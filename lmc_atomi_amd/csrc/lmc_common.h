@@ -56,6 +56,12 @@ struct StepArgs {
   // rows kernel only: dot_out[c] += sum_ij x_in[c][i][j] * x_out[c][i][j] (the p.Ap of a CG iteration, fused into the operator apply)
   double* dot_out;
   const int* skip_flag;
+  // rows kernel only: dot_mode 1 turns the fused reduction into the residual statistics of a Chebyshev step (lmc_capi.hip:
+  // chebyshev_solve): dot_out[2c] += sum (x_out - x_in)^2, dot_out[2c+1] += sum prox_ext^2.  run_count / run_index: the launch returns at
+  // once when *run_count <= run_index (the iterations a warm-started solve turned out not to need).
+  int dot_mode;
+  const int* run_count;
+  int run_index;
   // pipe kernel only: energies of x_in as by-products of the update (MYMALA): f_out[c] += sigma_f/2 ||H x - y||^2 (the residual rows
   // of the blur pipeline), g_out[c] += g_scale * TV_iso(x) (from the ring rows of the combine wave)
   double* f_out;

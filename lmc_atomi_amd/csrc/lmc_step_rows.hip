@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   if constexpr (DOT) {
     if (P.skip_flag && *P.skip_flag) return;            // CG operator apply after convergence (lmc_capi.hip: cg_solve_fused)
   }
+  if (P.run_count && *P.run_count <= P.run_index) return;   // Chebyshev iteration the solve does not need (uniform, one scalar load)
   const int lane = threadIdx.x & 63;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gw >= P.C * nbands) return;                       // whole waves leave; nothing below synchronises
@@ -105,7 +106,8 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
     rows_load_raw<PXL>(yq[(8 - LAG + d) & 3], P.y + (size_t)min(max(r, 0), H - 1) * W, c0, W);
   });
 
-  double dacc = 0.0;       // sum x_in * x_out over this wave's band (P.dot_out: the p.Ap of CG)
+  double dacc = 0.0;       // sum x_in * x_out over this wave's band (P.dot_out: the p.Ap of CG); dot_mode 1: sum (x_out - x_in)^2
+  double dacc2 = 0.0;      // dot_mode 1: sum prox_ext^2
 
   // One step = input row i = base + J (J = i & 7 is a compile-time constant: every ring slot below is static).
   // No step is conditional, so a ring slot is dead between its last read and the assignment that restarts it.
@@ -230,7 +232,14 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
               else if (P.prior_kind == LMC_PRIOR_L1) px = copysignf(fmaxf(fabsf(x) - P.prior_p0, 0.f), x);
               if (P.prox_ext) px = pe[q];
               ov[q] = fmaf(P.a, x, fmaf(-P.t, gr, fmaf(P.b, px, P.s * xi[q])));
-              if constexpr (DOT) dacc = fma((double)x, (double)ov[q], dacc);
+              if constexpr (DOT) {
+                if (P.dot_mode == 0) dacc = fma((double)x, (double)ov[q], dacc);
+                else {
+                  const double d = (double)ov[q] - (double)x;
+                  dacc = fma(d, d, dacc);
+                  dacc2 = fma((double)pe[q], (double)pe[q], dacc2);
+                }
+              }
             }
             *reinterpret_cast<float4*>(xout + go + c0 + 4 * g) = make_float4(ov[0], ov[1], ov[2], ov[3]);
           }
@@ -248,7 +257,12 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   static_for<0, LAG>([&](auto jj) { step(jj, r1r); });                          // drain: the last LAG output rows
   if constexpr (DOT) {
     const double tot = wave_sum(dacc);
-    if (lane == 0) unsafeAtomicAdd(&P.dot_out[chain], tot);
+    if (P.dot_mode == 0) {
+      if (lane == 0) unsafeAtomicAdd(&P.dot_out[chain], tot);
+    } else {
+      const double tot2 = wave_sum(dacc2);
+      if (lane == 0) { unsafeAtomicAdd(&P.dot_out[2 * chain], tot); unsafeAtomicAdd(&P.dot_out[2 * chain + 1], tot2); }
+    }
   }
 }
 

@@ -160,6 +160,29 @@ __global__ __launch_bounds__(256) void cg_check_kernel(int64_t C, const double* 
   if (threadIdx.x == 0 && ok) *done = 1;
 }
 
+// Number of Chebyshev launches a solve needs, from the statistics of its first launch (stat[2c] = sum (u_1 - u_0)^2 = alpha_0^2 |r_0|^2,
+// stat[2c+1] = |rhs|^2): the k-th iterate has |r_k| <= 2 c^k |r_0|, so k = ceil(log(2 |r_0| / (tol |rhs|)) / log(1/c)), at least the one
+// launch already done, rounded up to even (the ping-pong then ends in the caller's buffer), at most kmax; the maximum over the chains.
+__global__ __launch_bounds__(256) void cheb_count_kernel(int64_t C, const double* __restrict__ stat, double inv_alpha2, double tol,
+                                                         double inv_log_inv_c, int kmax, int* __restrict__ count) {
+  int need = 2;
+  for (int64_t c = threadIdx.x; c < C; c += blockDim.x) {
+    const double r2 = stat[2 * c] * inv_alpha2, b2 = stat[2 * c + 1];
+    int k = 1;
+    if (!(b2 > 0.0) || !(r2 == r2)) k = kmax;                       // no scale to compare with (or NaN): the a-priori count
+    else if (r2 > tol * tol * b2) k = (int)ceil(log(2.0 * sqrt(r2 / b2) / tol) * inv_log_inv_c);
+    k = (k + 1) & ~1;
+    need = max(need, min(k, kmax));
+  }
+  atomicMax(count, need);
+}
+
+hipError_t cheb_count(int64_t C, const double* stat, double inv_alpha2, double tol, double inv_log_inv_c, int kmax, int* count,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(cheb_count_kernel, dim3(1), dim3(256), 0, st, C, stat, inv_alpha2, tol, inv_log_inv_c, kmax, count);
+  return hipGetLastError();
+}
+
 // alpha = rs/pq ; u += alpha p ; r -= alpha q ; rs_new = dot(r, r)
 __global__ __launch_bounds__(256) void cg_update_kernel(float* __restrict__ u, float* __restrict__ r, const float* __restrict__ p,
                                                         const float* __restrict__ q, size_t img, const double* __restrict__ rs,
