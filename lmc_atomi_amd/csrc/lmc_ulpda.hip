@@ -284,14 +284,111 @@ hipError_t cg_check(int64_t C, const double* rsv, const double* b2, double tol2,
 
 // ---- host-side sequences --------------------------------------------------------------------------------
 
+// ---- 4 pixels per thread (W % 4 == 0): b128 accesses, one 32-bit division per thread instead of two 64-bit ones per pixel ----------
+// grid: x over groups of 4 pixels of one image, y over chains (chunks of 65535)
+
+__global__ __launch_bounds__(256) void ulpda_dual4_kernel(const float* __restrict__ xhat, float* __restrict__ y, int H, int W,
+                                                          float mu, float radius, int iso) {
+  const unsigned img = (unsigned)H * (unsigned)W;
+  const unsigned p = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+  if (p >= img) return;
+  const unsigned r = p / (unsigned)W, col = p - r * (unsigned)W;
+  const float* xc = xhat + (size_t)blockIdx.y * img;
+  float* yr = y + (size_t)blockIdx.y * 2 * img;
+  float* yc = yr + img;
+  const float4 v = *reinterpret_cast<const float4*>(xc + p);
+  const bool down = r + 1 < (unsigned)H;
+  const float4 vd = down ? *reinterpret_cast<const float4*>(xc + p + W) : v;       // last row: dx = v - v = 0
+  const float vr = (col + 4 < (unsigned)W) ? xc[p + 4] : v.w;                          // last column: dy = 0
+  const float4 a4 = *reinterpret_cast<const float4*>(yr + p);
+  const float4 b4 = *reinterpret_cast<const float4*>(yc + p);
+  float a[4] = {fmaf(mu, vd.x - v.x, a4.x), fmaf(mu, vd.y - v.y, a4.y), fmaf(mu, vd.z - v.z, a4.z), fmaf(mu, vd.w - v.w, a4.w)};
+  float b[4] = {fmaf(mu, v.y - v.x, b4.x), fmaf(mu, v.z - v.y, b4.y), fmaf(mu, v.w - v.z, b4.z), fmaf(mu, vr - v.w, b4.w)};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (iso) {
+      const float sc = 1.f / fmaxf(1.f, sqrtf(fmaf(a[k], a[k], b[k] * b[k])) / radius);
+      a[k] *= sc; b[k] *= sc;
+    } else {
+      a[k] = fminf(fmaxf(a[k], -radius), radius);
+      b[k] = fminf(fmaxf(b[k], -radius), radius);
+    }
+  }
+  *reinterpret_cast<float4*>(yr + p) = make_float4(a[0], a[1], a[2], a[3]);
+  *reinterpret_cast<float4*>(yc + p) = make_float4(b[0], b[1], b[2], b[3]);
+}
+
+__global__ __launch_bounds__(256) void ulpda_rhs4_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ z, const float* __restrict__ htb,
+                                                         float* __restrict__ rhs, int H, int W, float tau, float ts) {
+  const unsigned img = (unsigned)H * (unsigned)W;
+  const unsigned p = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+  if (p >= img) return;
+  const unsigned r = p / (unsigned)W, col = p - r * (unsigned)W;
+  const float* yr = y + (size_t)blockIdx.y * 2 * img;
+  const float* yc = yr + img;
+  const float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 ra = (r + 1 < (unsigned)H) ? *reinterpret_cast<const float4*>(yr + p) : z0;
+  const float4 rb = (r > 0) ? *reinterpret_cast<const float4*>(yr + p - W) : z0;
+  float4 ca = *reinterpret_cast<const float4*>(yc + p);
+  const float cl = (col > 0) ? yc[p - 1] : 0.f;
+  if (col + 4 >= (unsigned)W) ca.w = 0.f;                                             // last column of the column component counts as zero
+  // A^T y = -div y, terms in the order of the scalar kernel: -yr[p] + yr[p-W] - yc[p] + yc[p-1]
+  float aty[4] = {((0.f - ra.x) + rb.x - ca.x) + cl, ((0.f - ra.y) + rb.y - ca.y) + ca.x, ((0.f - ra.z) + rb.z - ca.z) + ca.y,
+                  ((0.f - ra.w) + rb.w - ca.w) + ca.z};
+  if (z) {
+    const float4 zz = *reinterpret_cast<const float4*>(z + p);
+    aty[0] += zz.x; aty[1] += zz.y; aty[2] += zz.z; aty[3] += zz.w;
+  }
+  const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)blockIdx.y * img + p);
+  float o[4] = {fmaf(-tau, aty[0], xv.x), fmaf(-tau, aty[1], xv.y), fmaf(-tau, aty[2], xv.z), fmaf(-tau, aty[3], xv.w)};
+  if (htb) {
+    const float4 hb = *reinterpret_cast<const float4*>(htb + p);
+    o[0] = fmaf(ts, hb.x, o[0]); o[1] = fmaf(ts, hb.y, o[1]); o[2] = fmaf(ts, hb.z, o[2]); o[3] = fmaf(ts, hb.w, o[3]);
+  }
+  *reinterpret_cast<float4*>(rhs + (size_t)blockIdx.y * img + p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ __launch_bounds__(256) void ulpda_finish4_kernel(float4* __restrict__ x, float4* __restrict__ xhat, const float4* __restrict__ u,
+                                                            const float4* __restrict__ xi, size_t total4, float s, float theta) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 xo = x[i];
+    float4 xn = u[i];
+    if (xi) { const float4 n = xi[i]; xn.x = fmaf(s, n.x, xn.x); xn.y = fmaf(s, n.y, xn.y); xn.z = fmaf(s, n.z, xn.z); xn.w = fmaf(s, n.w, xn.w); }
+    x[i] = xn;
+    xhat[i] = make_float4(fmaf(theta, xn.x - xo.x, xn.x), fmaf(theta, xn.y - xo.y, xn.y), fmaf(theta, xn.z - xo.z, xn.z),
+                          fmaf(theta, xn.w - xo.w, xn.w));
+  }
+}
+
+static inline bool vec4_ok(int H, int W) { return (W & 3) == 0 && (size_t)H * W < (1ull << 31); }
+
 hipError_t ulpda_dual_update(const float* xhat, float* y, int64_t C, int H, int W, float mu, float radius, int iso,
                              hipStream_t st) {
+  if (vec4_ok(H, W)) {
+    const size_t img = (size_t)H * W;
+    const unsigned gx = (unsigned)((img / 4 + 255) / 256);
+    for (int64_t c0 = 0; c0 < C; c0 += 65535) {
+      const unsigned nc = (unsigned)((C - c0) < 65535 ? (C - c0) : 65535);
+      hipLaunchKernelGGL(ulpda_dual4_kernel, dim3(gx, nc), dim3(256), 0, st, xhat + c0 * img, y + c0 * 2 * img, H, W, mu, radius, iso);
+    }
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(ulpda_dual_kernel, dim3(grid1d((size_t)H * W * C, 256)), dim3(256), 0, st, xhat, y, H, W, C, mu, radius, iso);
   return hipGetLastError();
 }
 
 hipError_t ulpda_rhs(const float* x, const float* y, const float* z, const float* htb, float* rhs, int64_t C, int H, int W,
                      float tau, float ts, hipStream_t st) {
+  if (vec4_ok(H, W)) {
+    const size_t img = (size_t)H * W;
+    const unsigned gx = (unsigned)((img / 4 + 255) / 256);
+    for (int64_t c0 = 0; c0 < C; c0 += 65535) {
+      const unsigned nc = (unsigned)((C - c0) < 65535 ? (C - c0) : 65535);
+      hipLaunchKernelGGL(ulpda_rhs4_kernel, dim3(gx, nc), dim3(256), 0, st, x + c0 * img, y + c0 * 2 * img, z, htb, rhs + c0 * img, H, W, tau, ts);
+    }
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(ulpda_rhs_kernel, dim3(grid1d((size_t)H * W * C, 256)), dim3(256), 0, st, x, y, z, htb, rhs, H, W, C, tau, ts);
   return hipGetLastError();
 }
@@ -306,6 +403,12 @@ hipError_t ulpda_pointwise_prox(const float* v, float* u, const float* b, const 
 hipError_t ulpda_finish(float* x, float* xhat, const float* u, const float* xi, int64_t C, int H, int W, float s, float theta,
                         hipStream_t st) {
   const size_t total = (size_t)H * W * C;
+  if ((((size_t)H * W) & 3) == 0) {
+    hipLaunchKernelGGL(ulpda_finish4_kernel, dim3(grid1d(total / 4, 256)), dim3(256), 0, st, reinterpret_cast<float4*>(x),
+                       reinterpret_cast<float4*>(xhat), reinterpret_cast<const float4*>(u), reinterpret_cast<const float4*>(xi), total / 4, s,
+                       theta);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(ulpda_finish_kernel, dim3(grid1d(total, 256)), dim3(256), 0, st, x, xhat, u, xi, total, s, theta);
   return hipGetLastError();
 }
