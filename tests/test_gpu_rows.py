@@ -40,7 +40,8 @@ def problem(shape, k, rng, gaussian=False):
 # widths: 4 px/lane (<= 256) and 8 px/lane (<= 512), partially filled last lanes, heights below the pipeline depth,
 # not multiples of 8, several bands per chain (H > 32)
 @pytest.mark.parametrize("shape,k", [((32, 32), 5), ((3, 8), 5), ((20, 24), 6), ((70, 100), 7), ((100, 64), 5), ((256, 256), 5),
-                                     ((45, 260), 5), ((130, 512), 5), ((9, 36), 3), ((41, 300), 3)])
+                                     ((45, 260), 5), ((130, 512), 5), ((9, 36), 3), ((41, 300), 3),
+                                     ((37, 512), 7), ((50, 384), 6), ((24, 264), 7)])     # 7 taps at 8 pixels per lane
 @pytest.mark.parametrize("prior", ["l2", "l1", "none"])
 def test_rows_kernel_matches_oracle_step(la, shape, k, prior):
     sigma, tau_reg = 0.75, 0.3

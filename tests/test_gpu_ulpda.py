@@ -183,7 +183,7 @@ def test_cg_early_exit_matches_fixed_iterations(la):
 
 
 @pytest.mark.parametrize("k,off,shape", [(5, (2, 2), (32, 64)), (5, (2, 2), (48, 264)), (7, (3, 3), (40, 128)), (6, (3, 3), (36, 200)),
-                                          (5, (2, 2), (64, 512)), (3, (1, 1), (33, 12))])
+                                          (5, (2, 2), (64, 512)), (3, (1, 1), (33, 12)), (7, (3, 3), (40, 512)), (6, (3, 3), (33, 384))])
 def test_l2_implicit_step_reaches_the_reference_tolerance(la, k, off, shape):
     """Shapes the row-streaming kernel covers: the implicit step is the Chebyshev semi-iteration (one launch per iteration, iteration
     count from the spectral bound).  The residual of the normal equations must meet the reference solver's stopping rule
