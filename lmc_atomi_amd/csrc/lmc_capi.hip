@@ -1061,14 +1061,19 @@ static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, h
       HIP_TRY(lmc::ulpda_pointwise_prox(s->rhs, s->uw, s->prob.y, s->prob.mask, C, H, W, ts, s->prob.data_kind, st));
       u = s->uw;
     }
-    const float* xi = nullptr;
-    if (s->noise_mode == LMC_NOISE_INJECTED) xi = noise_dev + (size_t)k * per_iter;
-    else if (s->noise_mode == LMC_NOISE_PHILOX) {
-      HIP_TRY(lmc::launch_noise(s->xi, (int)C, H, W, s->base.key0, s->base.key1, (uint32_t)s->iteration, s->base.chain_offset, st));
-      xi = s->xi;
-    }
     // x <- u + sqrt(2 tau) xi ; xhat <- x + theta (x - x_old)     (algs.py:440-441 / 446-447)
-    HIP_TRY(lmc::ulpda_finish(x, s->xhat, u, xi, C, H, W, std::sqrt(2.f * s->tau), s->theta, st));
+    if (s->noise_mode == LMC_NOISE_PHILOX && (W & 3) == 0) {     // the Philox field is drawn inside the pass
+      HIP_TRY(lmc::ulpda_finish_philox(x, s->xhat, u, C, H, W, std::sqrt(2.f * s->tau), s->theta, s->base.key0, s->base.key1,
+                                       (uint32_t)s->iteration, s->base.chain_offset, st));
+    } else {
+      const float* xi = nullptr;
+      if (s->noise_mode == LMC_NOISE_INJECTED) xi = noise_dev + (size_t)k * per_iter;
+      else if (s->noise_mode == LMC_NOISE_PHILOX) {
+        HIP_TRY(lmc::launch_noise(s->xi, (int)C, H, W, s->base.key0, s->base.key1, (uint32_t)s->iteration, s->base.chain_offset, st));
+        xi = s->xi;
+      }
+      HIP_TRY(lmc::ulpda_finish(x, s->xhat, u, xi, C, H, W, std::sqrt(2.f * s->tau), s->theta, st));
+    }
     if (!s->gfirst)  // (algs.py:448)
       HIP_TRY(lmc::ulpda_dual_update(s->xhat, s->ydual, C, H, W, s->mu, s->prob.prior_sigma, iso, st));
     if (s->moments && s->iteration >= s->burn_in && (s->iteration - s->burn_in) % s->thin == 0) {

@@ -77,6 +77,8 @@ hipError_t ulpda_ncvx_rhs(const float* v, const float* htb, float* rhs, int64_t 
                           hipStream_t st);
 hipError_t ulpda_pointwise_prox(const float* v, float* u, const float* b, const float* m, int64_t C, int H, int W, float ts,
                                 int kind, hipStream_t st);
+hipError_t ulpda_finish_philox(float* x, float* xhat, const float* u, int64_t C, int H, int W, float s, float theta, uint32_t key0,
+                               uint32_t key1, uint32_t iteration, uint32_t chain_offset, hipStream_t st);
 hipError_t ulpda_finish(float* x, float* xhat, const float* u, const float* xi, int64_t C, int H, int W, float s, float theta,
                         hipStream_t st);
 hipError_t cg_dot(const float* p, const float* q, int64_t C, size_t img, double* pq, const int* done, hipStream_t st);

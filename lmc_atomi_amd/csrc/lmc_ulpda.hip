@@ -361,6 +361,47 @@ __global__ __launch_bounds__(256) void ulpda_finish4_kernel(float4* __restrict__
   }
 }
 
+// finish with the Philox field drawn in place (no noise buffer, no separate noise pass): one thread = a 4 x 4 block = four quads of the
+// counter layout shared by every kernel (ctr = (quad, iteration, global chain, stream tag), one quad = 4 rows of one column).
+__global__ __launch_bounds__(256) void ulpda_finish_philox_kernel(float* __restrict__ x, float* __restrict__ xhat, const float* __restrict__ u,
+                                                                  int H, int W, float s, float theta, uint32_t key0, uint32_t key1,
+                                                                  uint32_t iteration, uint32_t chain_offset) {
+  const unsigned w4 = (unsigned)W >> 2, nq = ((unsigned)H + 3u) >> 2;
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= w4 * nq) return;
+  const unsigned q = t / w4, g = t - q * w4;
+  const size_t base = (size_t)blockIdx.y * H * W;
+  float n[4][4];                                   // [column][row]
+#pragma unroll
+  for (int c = 0; c < 4; ++c) quad_normals(key0, key1, iteration, chain_offset + blockIdx.y, q * (unsigned)W + 4u * g + c, n[c]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned r = 4u * q + j;
+    if (r < (unsigned)H) {
+      const size_t i = base + (size_t)r * W + 4u * g;
+      const float4 xo = *reinterpret_cast<const float4*>(x + i);
+      const float4 uu = *reinterpret_cast<const float4*>(u + i);
+      const float4 xn = make_float4(fmaf(s, n[0][j], uu.x), fmaf(s, n[1][j], uu.y), fmaf(s, n[2][j], uu.z), fmaf(s, n[3][j], uu.w));
+      *reinterpret_cast<float4*>(x + i) = xn;
+      *reinterpret_cast<float4*>(xhat + i) = make_float4(fmaf(theta, xn.x - xo.x, xn.x), fmaf(theta, xn.y - xo.y, xn.y),
+                                                         fmaf(theta, xn.z - xo.z, xn.z), fmaf(theta, xn.w - xo.w, xn.w));
+    }
+  }
+}
+
+hipError_t ulpda_finish_philox(float* x, float* xhat, const float* u, int64_t C, int H, int W, float s, float theta, uint32_t key0,
+                               uint32_t key1, uint32_t iteration, uint32_t chain_offset, hipStream_t st) {
+  if (W & 3) return hipErrorInvalidConfiguration;
+  const size_t img = (size_t)H * W;
+  const unsigned gx = (unsigned)(((size_t)(W >> 2) * ((H + 3) >> 2) + 255) / 256);
+  for (int64_t c0 = 0; c0 < C; c0 += 65535) {
+    const unsigned nc = (unsigned)((C - c0) < 65535 ? (C - c0) : 65535);
+    hipLaunchKernelGGL(ulpda_finish_philox_kernel, dim3(gx, nc), dim3(256), 0, st, x + c0 * img, xhat + c0 * img, u + c0 * img, H, W, s, theta,
+                       key0, key1, iteration, chain_offset + (uint32_t)c0);
+  }
+  return hipGetLastError();
+}
+
 static inline bool vec4_ok(int H, int W) { return (W & 3) == 0 && (size_t)H * W < (1ull << 31); }
 
 hipError_t ulpda_dual_update(const float* xhat, float* y, int64_t C, int H, int W, float mu, float radius, int iso,
