@@ -204,3 +204,28 @@ def test_l2_implicit_step_reaches_the_reference_tolerance(la, k, off, shape):
             assert np.linalg.norm(res[c]) <= 3e-6 * np.linalg.norm(rhs[c]), (rep, c, np.linalg.norm(res[c]) / np.linalg.norm(rhs[c]))
     l2o = O.L2(Op=O.Convolve2D(shape, h, off), b=b.ravel(), sigma=sig, niter=300, warm=False)
     assert rel(u[1].ravel(), l2o.prox(v[1].ravel(), tau)) < 5e-6
+
+
+@pytest.mark.parametrize("gfirst", [True, False])
+@pytest.mark.parametrize("shape,iso", [((24, 40), True), ((17, 64), False), ((9, 10), True)])
+def test_ulpda_batched_step_equals_single_steps(la, gfirst, shape, iso):
+    """step(n) must leave exactly the primal and dual state of n calls of step(1), however the iterations are grouped into calls."""
+    rng = np.random.default_rng(5)
+    h = np.ones((5, 5)) / 25.0
+    b = rng.normal(100, 20, shape)
+    x0 = rng.normal(100, 20, (3,) + shape)
+    y0 = rng.normal(0, 0.2, (3, 2) + shape)
+    z = rng.normal(0, 0.1, shape) if not gfirst else None
+    outs = []
+    for chunks in ([7], [1] * 7, [3, 4]):
+        pf = la.L2(Op=la.Convolve2D(shape, h, offset=(2, 2)), b=b.ravel(), sigma=1 / 0.75 ** 2, niter=50, warm=True)
+        pg = la.L21(ndim=2, sigma=0.3) if iso else la.L1(sigma=0.3)
+        smp = la.ULPDASampler(pf, pg, la.Gradient(shape), shape, n_chains=3, tau=0.5, mu=0.9, theta=1.0, gfirst=gfirst, seed=9, z=z)
+        smp.set_state(x0)
+        smp.set_dual(y0)
+        for n in chunks:
+            smp.step(n)
+        outs.append((smp.get_state().cpu().numpy(), smp.get_dual().cpu().numpy()))
+        smp.close()
+    for xs, ys in outs[1:]:
+        assert np.array_equal(xs, outs[0][0]) and np.array_equal(ys, outs[0][1])
