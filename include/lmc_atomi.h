@@ -126,9 +126,12 @@ int lmc_fused_eval(const lmc_problem* prob, const float* x_dev, float* out_dev, 
                    float a, float t, float b, float pt, void* stream);
 
 /* Implicit data step  out = prox_{tau f}(x) = (I + tau*sigma_f*Op^T Op)^{-1} (x + tau*sigma_f*Op^T y)  for n_img images:
- * pyproximal.L2.prox / algs.py:224-256 (row a8).  LMC_DATA_BLUR: `niter` conjugate-gradient iterations started from
- * `out` as given if warm != 0, else from zero (the reference: LSQR, niter=50, warm start; build-specified solver).
- * IDENTITY / MASK / NONE: closed form.  workspace_dev: 5*n_img*H*W floats followed (8-byte aligned) by 3*n_img doubles;
+ * pyproximal.L2.prox / algs.py:224-256 (row a8).  LMC_DATA_BLUR: iterative, started from `out` as given if warm != 0, else from zero,
+ * to the relative residual of lmc_set_cg_tolerance within at most `niter` iterations (the reference: LSQR, niter=50, warm start).
+ * Build-specified solver: the Chebyshev semi-iteration on the known spectrum [1, 1 + tau*sigma_f*(sum|h|)^2] where the row-streaming
+ * kernel covers the blur (separable, <= 7 centred taps, W % 4 == 0, W <= 512) and the tolerance is reachable within `niter`;
+ * conjugate gradients otherwise (then a cap that binds returns CG's truncated iterate).
+ * IDENTITY / MASK / NONE: closed form.  workspace_dev: 5*n_img*H*W floats followed (8-byte aligned) by 4*n_img+1 doubles;
  * lmc_l2_prox_workspace_bytes gives the size. */
 size_t lmc_l2_prox_workspace_bytes(int64_t n_img, int32_t H, int32_t W);
 int lmc_l2_prox(const lmc_problem* prob, const float* x_dev, float* out_dev, int64_t n_img, float tau, int32_t niter,
@@ -241,8 +244,9 @@ const char* lmc_sampler_kernel_name(const lmc_sampler* s);
  *   xhat <- x + theta (x - x_old)                                   (:441/447)
  *   y    <- prox_{mu g*}(y + mu A xhat)                             (:436/448)   order set by gfirst (:435)
  * A = forward-difference gradient (prox_lmc_deconv.py:98); g = problem.prior (TV_ISO -> L21, TV_ANISO -> L1);
- * f = problem data term; for LMC_DATA_BLUR the implicit step (I + tau*sigma_f*H^T H)^{-1} is `cg_niter`
- * warm-started conjugate-gradient iterations per chain (the reference: <= 50 LSQR iterations, algs.py:247-256).
+ * f = problem data term; for LMC_DATA_BLUR the implicit step (I + tau*sigma_f*H^T H)^{-1} is solved per chain, warm-started, to the
+ * tolerance of lmc_set_cg_tolerance within at most `cg_niter` iterations (Chebyshev semi-iteration or CG, see lmc_l2_prox; the
+ * reference: <= 50 LSQR iterations, algs.py:247-256).
  * The handle is an lmc_sampler: set_state / get_state / step / energies / moments / noise / destroy apply. */
 typedef struct lmc_ulpda_config {
   uint32_t struct_size;     /* = sizeof(lmc_ulpda_config) */
@@ -266,9 +270,9 @@ int lmc_sampler_get_dual(lmc_sampler* s, float* y_dev, void* stream);
 /* change (tau, mu) for the following iterations (the reference accepts per-iteration arrays, algs.py:402-408) */
 int lmc_sampler_set_steps(lmc_sampler* s, float tau, float mu);
 
-/* Relative residual |r| <= tol |b| at which the inner conjugate-gradient solver of the implicit data step (lmc_l2_prox, ULPDA)
- * stops before cg_niter / niter iterations -- the stopping rule of the reference's solver (scipy lsqr's btol, default 1e-6, at
- * algs.py:250).  The test runs on the device for the whole batch of chains (all must satisfy it); tol = 0 disables it.
+/* Relative residual |r| <= tol |b| at which the inner solver of the implicit data step (lmc_l2_prox, ULPDA) stops before
+ * cg_niter / niter iterations -- the stopping rule of the reference's solver (scipy lsqr's btol, default 1e-6, at algs.py:250).
+ * Decided on the device for the whole batch of chains (all must satisfy it); tol = 0 disables it (always CG, all iterations).
  * Default 1e-6.  Returns the previous value; a negative argument only queries. */
 float lmc_set_cg_tolerance(float tol);
 
