@@ -101,5 +101,6 @@ hipError_t mala_propose_philox(const float* mx, float* xp, int64_t C, int H, int
 hipError_t mala_accept(int C, double* U, const double* fp, const double* gp, const double* d1, const double* d2, float tau,
                        uint32_t key0, uint32_t key1, uint32_t iteration, uint32_t chain_offset, int* flag,
                        unsigned long long* nacc, double* log_alpha, hipStream_t st);
-hipError_t mala_select(const int* flag, float* x, float* mx, const float* xp, const float* mxp, int64_t C, size_t img, hipStream_t st);
+hipError_t mala_select(const int* flag, float* x, float* mx, const float* xp, const float* mxp, int64_t C, size_t img, int when,
+                       hipStream_t st);
 }  // namespace lmc

@@ -104,21 +104,39 @@ hipError_t mala_accept(int C, double* U, const double* fp, const double* gp, con
   return hipGetLastError();
 }
 
-// accepted chains: x <- xp, mx <- mxp
-__global__ __launch_bounds__(256) void mala_select_kernel(const int* __restrict__ flag, float* __restrict__ x, float* __restrict__ mx,
-                                                          const float* __restrict__ xp, const float* __restrict__ mxp, size_t img) {
+// chains whose flag equals `when`: x <- xp, mx <- mxp   (when = 1: accepted chains take the proposal; when = 0, after the caller has swapped
+// the roles of the buffer pairs: rejected chains get their old state back -- the cheaper direction once most proposals are accepted)
+__global__ __launch_bounds__(256) void mala_select_kernel(const int* __restrict__ flag, float4* __restrict__ x, float4* __restrict__ mx,
+                                                          const float4* __restrict__ xp, const float4* __restrict__ mxp, size_t img4, int when) {
   const size_t c = blockIdx.y;
-  if (!flag[c]) return;
+  if ((flag[c] != 0) != (when != 0)) return;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img4; k += (size_t)gridDim.x * blockDim.x) {
+    x[c * img4 + k] = xp[c * img4 + k];
+    mx[c * img4 + k] = mxp[c * img4 + k];
+  }
+}
+
+__global__ __launch_bounds__(256) void mala_select1_kernel(const int* __restrict__ flag, float* __restrict__ x, float* __restrict__ mx,
+                                                           const float* __restrict__ xp, const float* __restrict__ mxp, size_t img, int when) {
+  const size_t c = blockIdx.y;
+  if ((flag[c] != 0) != (when != 0)) return;
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.x * blockDim.x) {
     x[c * img + k] = xp[c * img + k];
     mx[c * img + k] = mxp[c * img + k];
   }
 }
 
-hipError_t mala_select(const int* flag, float* x, float* mx, const float* xp, const float* mxp, int64_t C, size_t img, hipStream_t st) {
+hipError_t mala_select(const int* flag, float* x, float* mx, const float* xp, const float* mxp, int64_t C, size_t img, int when, hipStream_t st) {
+  if ((img & 3) == 0) {
+    int gx = (int)((img / 4 + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(mala_select_kernel, dim3(gx, (unsigned)C), dim3(256), 0, st, flag, reinterpret_cast<float4*>(x), reinterpret_cast<float4*>(mx),
+                       reinterpret_cast<const float4*>(xp), reinterpret_cast<const float4*>(mxp), img / 4, when);
+    return hipGetLastError();
+  }
   int gx = (int)((img + 255) / 256);
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(mala_select_kernel, dim3(gx, (unsigned)C), dim3(256), 0, st, flag, x, mx, xp, mxp, img);
+  hipLaunchKernelGGL(mala_select1_kernel, dim3(gx, (unsigned)C), dim3(256), 0, st, flag, x, mx, xp, mxp, img, when);
   return hipGetLastError();
 }
 
