@@ -37,3 +37,20 @@ def test_driver_mymala_branch():
     res = prox_lmc_deconv(N=20, image=img, alg="MYMALA", seed=0, n_chains=4, models=["M1", "M2", "M3"], verbose=False, niter_l2=10)
     for m in ("M1", "M2", "M3"):
         assert np.all(np.isfinite(res[m]["mean"])) and res[m]["mean"].shape == img.shape
+
+
+def test_reference_form_is_the_same_with_and_without_a_callback():
+    """A callback must not change the iterates (one chain, every iterate returned, both noise sources)."""
+    import lmc_atomi_amd as la
+    rng = np.random.default_rng(4)
+    shape = (16, 24)
+    y = rng.uniform(50, 200, shape)
+    pf = la.L2(Op=la.Convolve2D(shape, np.ones((5, 5)) / 25.0, offset=(2, 2)), b=y.ravel(), sigma=1 / 0.5625)
+    pg = la.TV(shape, sigma=0.3, niter=10)
+    seen = []
+    for r in ("philox", "pcg64"):
+        a = la.MoreauYosidaUnadjustedLangevin(pf, pg, np.zeros(shape[0] * shape[1]), tau=0.1125, gamma=0.5625, niter=9, seed=3, rng=r)
+        b = la.MoreauYosidaUnadjustedLangevin(pf, pg, np.zeros(shape[0] * shape[1]), tau=0.1125, gamma=0.5625, niter=9, seed=3, rng=r,
+                                              callback=lambda x: seen.append(float(x[0])))
+        assert a.shape == (9, shape[0] * shape[1]) and np.array_equal(a, b)
+    assert len(seen) == 18
