@@ -229,3 +229,27 @@ def test_ulpda_batched_step_equals_single_steps(la, gfirst, shape, iso):
         smp.close()
     for xs, ys in outs[1:]:
         assert np.array_equal(xs, outs[0][0]) and np.array_equal(ys, outs[0][1])
+
+
+@pytest.mark.parametrize("tau,scale,signed", [(5.0, 1.0, False), (0.53, 1.7, False), (0.53, 1.0, True), (40.0, 1.0, False)])
+def test_l2_implicit_step_spectral_bound_holds(la, tau, scale, signed):
+    """The Chebyshev iteration relies on spec(H^T H) <= (sum |h|)^2: large steps (condition number ~ 10 and, at tau = 40, ~ 70: too many
+    iterations for the cap, so CG takes over), kernels that do not sum to one, kernels with negative taps."""
+    rng = np.random.default_rng(11)
+    shape = (40, 64)
+    u1, u2 = rng.uniform(0.5, 1.5, 5), rng.uniform(0.5, 1.5, 5)
+    if signed:
+        u1[1] *= -1.0
+        u2[3] *= -1.0
+    h = np.outer(u1, u2)
+    h *= scale / np.abs(h).sum()
+    b = rng.normal(100, 20, shape)
+    v = rng.normal(100, 20, (2,) + shape)
+    sig = 1 / 0.75 ** 2
+    l2 = la.L2(Op=la.Convolve2D(shape, h, offset=(2, 2)), b=b.ravel(), sigma=sig, niter=50, warm=False)
+    ts = tau * sig
+    u = np.asarray(l2.prox(v.reshape(2, -1), tau), dtype=np.float64).reshape((2,) + shape)
+    rhs = v + ts * O.blur_adjoint(b, h, (2, 2))[None]
+    res = rhs - (u + ts * O.blur_adjoint(O.blur(u, h, (2, 2)), h, (2, 2)))
+    for c in range(2):
+        assert np.linalg.norm(res[c]) <= 5e-6 * np.linalg.norm(rhs[c]), np.linalg.norm(res[c]) / np.linalg.norm(rhs[c])
