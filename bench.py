@@ -120,6 +120,11 @@ def main():
             sys.exit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N (one rank per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # rehearsal of the N > 1 code on a one-GPU box: LMC_BENCH_DEVICE=0 puts every rank on GPU 0, LMC_BENCH_BACKEND=gloo replaces RCCL
+    # (which refuses two ranks on one GPU); the numbers of such a run mean nothing
+    backend = os.environ.get("LMC_BENCH_BACKEND", "nccl")
+    if os.environ.get("LMC_BENCH_DEVICE"):
+        local_rank = int(os.environ["LMC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     # LMC_BENCH_DIST=1 forces the RCCL path (process group, barrier, moment all-reduce, max-over-ranks) at world size 1:
     # the rehearsal of the N > 1 code on a one-GPU box
@@ -127,7 +132,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import lmc_atomi_amd as la
     if os.environ.get("LMC_VARIANT"):                # A/B runs of the step-kernel variants (scripts/bench_variants.py)
@@ -188,7 +196,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     if timed_launches:

@@ -29,11 +29,14 @@ def allreduce_moments(s1: torch.Tensor, s2: torch.Tensor, count: int, group=None
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return s1, s2, int(count)
     n = s1.numel()
-    packed = torch.empty(2 * n + 1, dtype=torch.float64, device=s1.device)
-    packed[:n] = s1.reshape(-1)
-    packed[n:2 * n] = s2.reshape(-1)
+    # "gloo" (CPU tests, and the two-ranks-on-one-GPU rehearsal of bench.py) reduces host tensors; "nccl" = RCCL reduces in HBM
+    dev = torch.device("cpu") if (dist.get_backend(group) == "gloo" and s1.is_cuda) else s1.device
+    packed = torch.empty(2 * n + 1, dtype=torch.float64, device=dev)
+    packed[:n] = s1.reshape(-1).to(dev)
+    packed[n:2 * n] = s2.reshape(-1).to(dev)
     packed[2 * n] = float(count)
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    packed = packed.to(s1.device)
     return packed[:n].reshape(s1.shape), packed[n:2 * n].reshape(s2.shape), int(round(float(packed[2 * n])))
 
 
