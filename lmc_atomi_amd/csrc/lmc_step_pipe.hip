@@ -240,6 +240,26 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
         gload_raw<PXL>(ypre[u], A.y + (size_t)min(max(r, 0), H - 1) * W, c0, W);
       }
     }
+    // Without a blur: pointwise data terms (identity, diagonal mask).  Their gradient sigma_f m (m x - y) of row t + 1 - D -- the row the
+    // combine wave emits next tick -- is formed HERE (this wave issues no stores, so its loads never queue behind stores in vmcnt) from
+    // the ring copy of x and the observation / mask rows requested kYPF ticks ahead, and handed over through the same o_g slots as the
+    // blur gradient.
+    const bool pw_id = KT == 0 && A.data_kind == LMC_DATA_IDENTITY, pw_mask = KT == 0 && A.data_kind == LMC_DATA_MASK;
+    float mpre[KT == 0 ? 4 : 1][KT == 0 ? PXL : 1];
+    if constexpr (KT == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) { ypre[u][k] = 0.f; mpre[u][k] = 0.f; }
+      if (pw_id || pw_mask) {
+#pragma unroll
+        for (int u = 0; u < kYPF; ++u) {
+          const size_t ro = (size_t)min(max(u + 1 - D, 0), H - 1) * W;
+          gload_raw<PXL>(ypre[u], A.y + ro, c0, W);
+          if (pw_mask) gload_raw<PXL>(mpre[u], A.mask + ro, c0, W);
+        }
+      }
+    }
     // chained launch: the dual state rows for stage 1, fetched two ticks ahead (row t - E - 1 is published at tick t)
     float spre[CHAIN ? 2 : 1][CHAIN ? 4 : 1][CHAIN ? PXL : 1];
     const float* const sin = CHAIN && A.tv_in ? A.tv_in + (size_t)chain * 4 * img : nullptr;
@@ -258,6 +278,10 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
       if constexpr (KT > 0) {   // observation row of the residual row kYPF ticks from now
         const int r3 = t + kYPF + 1 - D + (KT - 1) - HW;
         gload_raw<PXL>(ypre[(U + kYPF) & 3], A.y + (size_t)min(max(r3, 0), H - 1) * W, c0, W);
+      } else if (pw_id || pw_mask) {
+        const size_t ro = (size_t)min(max(t + kYPF + 1 - D, 0), H - 1) * W;
+        gload_raw<PXL>(ypre[(U + kYPF) & 3], A.y + ro, c0, W);
+        if (pw_mask) gload_raw<PXL>(mpre[(U + kYPF) & 3], A.mask + ro, c0, W);
       }
       {   // row t arrives: publish it in the ring (zeros below the image); fetch row t + 4
         float xv[PXL];
@@ -345,6 +369,24 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
         prow_store<PXL>(lds + L::o_g + P * BW, lane, gout);      // row t + 1 - D, read by C next tick
       }
       }   // KT > 0
+      if constexpr (KT == 0) {
+        if (pw_id || pw_mask) {
+          const int i = t + 1 - D;                // <= t - 1: published in an earlier tick
+          float xi[PXL], gout[PXL];
+          prow_load<PXL>(xi, ring_row(i), lane);
+          const bool rowok = i >= 0 && i < H;
+#pragma unroll
+          for (int k = 0; k < PXL; ++k) {
+            float g = 0.f;
+            if (rowok && c0 + (k & ~3) < W) {
+              if (pw_id) g = A.sigma_f * (xi[k] - ypre[U & 3][k]);
+              else g = A.sigma_f * mpre[U & 3][k] * fmaf(mpre[U & 3][k], xi[k], -ypre[U & 3][k]);
+            }
+            gout[k] = g;
+          }
+          prow_store<PXL>(lds + L::o_g + P * BW, lane, gout);      // row t + 1 - D, read by C next tick
+        }
+      }
       PIPE_TICK_SYNC();
     };
     for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
@@ -496,9 +538,9 @@ __global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void
       prow_load<PXL>(crr[P], hin + (P ^ 1) * HSTR, lane);            // rr^K on row o (written last tick)
       prow_load<PXL>(css, hin + (P ^ 1) * HSTR + BW, lane);
       prow_load<PXL>(xo, ring_row(o), lane);
-      if constexpr (KT > 0) {
+      if (KT > 0 || A.data_kind == LMC_DATA_IDENTITY || A.data_kind == LMC_DATA_MASK) {
         prow_load<PXL>(gv, lds + L::o_g + (P ^ 1) * BW, lane);
-      } else {                                  // no blur wave output: o_g was never written (stale LDS could hold NaN bit patterns)
+      } else {                                  // no data term: o_g is never written (stale LDS could hold NaN bit patterns)
 #pragma unroll
         for (int j = 0; j < PXL; ++j) gv[j] = 0.f;
       }
@@ -591,11 +633,11 @@ int pipe_links(const StepArgs& a) {
   if (a.data_kind == LMC_DATA_BLUR) {
     float uc[kMaxBlur], vc[kMaxBlur];
     if (centred_blur_taps(a, uc, vc) == 0) return 0;
-  } else if (a.data_kind != LMC_DATA_NONE) {
-    return 0;                                  // pointwise data terms: split kernel (forming them in the combine wave here was measured:
-                                               // 2.5 (identity) / 2.9 ms (mask) against 2.44 ms for the split kernel -- the combine wave then waits on vmcnt)
+  } else if (a.data_kind != LMC_DATA_NONE && a.data_kind != LMC_DATA_IDENTITY && a.data_kind != LMC_DATA_MASK) {
+    return 0;
   }
-  if (a.data_kind == LMC_DATA_NONE && (a.ncvx_kind != LMC_NCVX_NONE || a.f_out)) return 0;
+  // without a blur (no data term, or a pointwise one formed in the load wave): no extra gradient terms, no energy by-products
+  if (a.data_kind != LMC_DATA_BLUR && (a.ncvx_kind != LMC_NCVX_NONE || a.f_out)) return 0;
   return single ? 1 : a.tv.niter / 10;
 }
 

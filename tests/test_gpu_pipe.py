@@ -229,3 +229,35 @@ def test_pipe_kernel_fewer_dual_iterations(la, shape, K):
         smp.close()
     la.set_step_variant("auto")
     assert rel(outs["auto"], outs["tile"]) < 2e-6
+
+
+@pytest.mark.parametrize("data", ["mask", "identity"])
+@pytest.mark.parametrize("shape,K", [((40, 264), 10), ((33, 512), 10), ((21, 200), 6), ((5, 136), 2), ((1, 256), 10)])
+def test_pipe_kernel_pointwise_data_terms(la, data, shape, K):
+    """Inpainting (diagonal mask) and denoising (identity) data terms with the TV prior: their gradient is formed in the load wave of the
+    instantiation without a blur; against the oracle step with injected noise."""
+    sigma, tau_reg = 0.75, 0.3
+    gamma, tau = sigma ** 2, 0.2 * sigma ** 2
+    rng = np.random.default_rng(61)
+    C, nit = 2, 3
+    img = problem(shape, rng)[0]
+    mask = (rng.uniform(size=shape) < 0.6).astype(np.float64) if data == "mask" else None
+    y = (mask * img if mask is not None else img) + rng.normal(0, sigma, shape) * (mask if mask is not None else 1.0)
+    if mask is not None:
+        pf = la.L2(Op=la.Diagonal(mask, dims=shape), b=y, sigma=1 / sigma ** 2, dims=shape)
+    else:
+        pf = la.L2(b=y, sigma=1 / sigma ** 2, dims=shape)
+    op = {"kind": "tv", "sigma": tau_reg, "niter": K, "t": gamma}
+    x0 = img[None] + rng.normal(0, 10, (C,) + shape)
+    noise = rng.standard_normal((nit, C) + shape)
+    la.set_step_variant("auto")
+    smp = la.MYULASampler(pf, la.TV(shape, sigma=tau_reg, niter=K), shape, n_chains=C, tau=tau, gamma=gamma, noise="injected")
+    smp.set_state(x0)
+    x = x0.copy()
+    for it in range(nit):
+        smp.step(1, noise=noise[it:it + 1])
+        x = O.myula_step(x, y, None, None, 1 / sigma ** 2, tau, gamma, op, noise[it], mask=mask)
+        got = smp.get_state().cpu().numpy()
+        assert rel(got, x) < 2e-6 * (it + 1), (it, rel(got, x))
+    assert smp.kernel_name == "myula_step_pipe_kernel", smp.kernel_name
+    smp.close()
