@@ -371,6 +371,16 @@ __global__ __launch_bounds__(256) void ulpda_finish_philox_kernel(float* __restr
   if (t >= w4 * nq) return;
   const unsigned q = t / w4, g = t - q * w4;
   const size_t base = (size_t)blockIdx.y * H * W;
+  // all loads first (in flight under the Philox arithmetic), then all stores: stores count in vmcnt like loads and complete in order with
+  // them, so a load issued after a store of this lane would wait for that store
+  float4 xo[4], uu[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned r = min(4u * q + j, (unsigned)H - 1u);
+    const size_t i = base + (size_t)r * W + 4u * g;
+    xo[j] = *reinterpret_cast<const float4*>(x + i);
+    uu[j] = *reinterpret_cast<const float4*>(u + i);
+  }
   float n[4][4];                                   // [column][row]
 #pragma unroll
   for (int c = 0; c < 4; ++c) quad_normals(key0, key1, iteration, chain_offset + blockIdx.y, q * (unsigned)W + 4u * g + c, n[c]);
@@ -379,12 +389,10 @@ __global__ __launch_bounds__(256) void ulpda_finish_philox_kernel(float* __restr
     const unsigned r = 4u * q + j;
     if (r < (unsigned)H) {
       const size_t i = base + (size_t)r * W + 4u * g;
-      const float4 xo = *reinterpret_cast<const float4*>(x + i);
-      const float4 uu = *reinterpret_cast<const float4*>(u + i);
-      const float4 xn = make_float4(fmaf(s, n[0][j], uu.x), fmaf(s, n[1][j], uu.y), fmaf(s, n[2][j], uu.z), fmaf(s, n[3][j], uu.w));
+      const float4 xn = make_float4(fmaf(s, n[0][j], uu[j].x), fmaf(s, n[1][j], uu[j].y), fmaf(s, n[2][j], uu[j].z), fmaf(s, n[3][j], uu[j].w));
       *reinterpret_cast<float4*>(x + i) = xn;
-      *reinterpret_cast<float4*>(xhat + i) = make_float4(fmaf(theta, xn.x - xo.x, xn.x), fmaf(theta, xn.y - xo.y, xn.y),
-                                                         fmaf(theta, xn.z - xo.z, xn.z), fmaf(theta, xn.w - xo.w, xn.w));
+      *reinterpret_cast<float4*>(xhat + i) = make_float4(fmaf(theta, xn.x - xo[j].x, xn.x), fmaf(theta, xn.y - xo[j].y, xn.y),
+                                                         fmaf(theta, xn.z - xo[j].z, xn.z), fmaf(theta, xn.w - xo[j].w, xn.w));
     }
   }
 }
