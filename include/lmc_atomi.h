@@ -16,6 +16,9 @@
  *  - the caller owns every buffer it passes; a sampler owns its state/scratch buffers.
  *  - calls on one sampler handle must be serialised by the caller; all work is enqueued on
  *    the given stream; functions that return host values synchronise that stream.
+ *  - devices: a sampler lives on the device that is current when it is created and every call on the handle runs there
+ *    (the library switches to that device for the duration of the call and restores the caller's; `stream` and the buffers
+ *    passed must belong to it).  The stateless operator entry points run on the caller's current device.
  */
 #ifndef LMC_ATOMI_H
 #define LMC_ATOMI_H
@@ -27,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMC_ATOMI_ABI_VERSION 1
+#define LMC_ATOMI_ABI_VERSION 2
 
 typedef enum lmc_status {
   LMC_OK = 0,
@@ -98,6 +101,29 @@ typedef struct lmc_problem {
   float ncvx_lambda;        /* lamda (= tau_reg at prox_lmc_deconv.py:106) */
   float ncvx_gamma;         /* gamma (= gamma_mc = gamma_me = 15 at prox_lmc_deconv.py:40,106,111) */
   int32_t ncvx_niter;       /* LMC_NCVX_ME_TV: dual iterations of the inner TV prox */
+  /* ---- ABI 2 ---- */
+  /* Which truncated iterate the TV prox returns.  pyproximal.TV.prox forms `sol = x - gamma div(r, s)` at the TOP of each loop pass and
+   * returns the `sol` of the pass it leaves in; whether a run of `niter` reflects niter or niter - 1 dual updates depends on the loop
+   * bound of the (un-vendored, un-pinned) upstream version -- it cannot be settled in this image.
+   * 0 (default): after tv_niter dual updates; 1: after tv_niter - 1 ("lagged": one pipeline stage fewer).  Applies to the
+   * LMC_PRIOR_TV_ISO prox and to the inner prox of the ME-TV term. */
+  int32_t tv_lagged_output;
+  /* pyproximal.TV's per-image early exit on the relative change of the primal objective (its default rtol = 1e-4).  A batched launch
+   * runs the same number of dual iterations for every chain: only 0 (off) is accepted, anything else is LMC_E_UNSUPPORTED -- the
+   * Python drop-in warns and passes 0 (parity holds at rtol = 0; measured divergence in DESIGN section 4). */
+  float tv_rtol;
+  /* Step-kernel variant for launches configured from this problem: 0 = the library default (lmc_set_step_variant, itself "auto"
+   * unless changed), 1..7 as listed at lmc_set_step_variant. */
+  int32_t step_variant;
+  /* Relative residual |r| <= tol |b| of the implicit data step (lmc_l2_prox, ULPDA): 0 = the library default
+   * (lmc_set_cg_tolerance, itself 1e-6 unless changed), > 0 explicit, < 0 disabled (always all iterations, CG). */
+  float implicit_tol;
+  /* MYULA samplers only (build extension; NOT the reference's algorithm, whose pyproximal.TV.prox starts every call from a zero dual):
+   * != 0 carries the projected TV dual (p, q) from one MYULA iteration to the next -- tv_niter in {1, 2, 3, 9, 10} dual iterations per
+   * MYULA iteration, momentum restarted, +16 B per pixel and iteration of HBM traffic for the dual field.  SURVEY section 8(d) "K in
+   * {1,3} warm-dual reported too".  lmc_sampler_set_state resets the dual to zero.  Needs the full-width pipeline kernel
+   * (132 <= W <= 512, separable blur / pointwise / no data term), otherwise LMC_E_UNSUPPORTED. */
+  int32_t tv_warm;
 } lmc_problem;
 
 /* ---- library ------------------------------------------------------------------------- */
@@ -201,10 +227,10 @@ void lmc_sampler_destroy(lmc_sampler* s);
 
 /* MYMALA -- the Metropolis-adjusted MYULA of prox_lmc.py:134-158 at image scale, every chain at once, same configuration
  * struct.  Per iteration and chain: x' = m(x) + sqrt(2 tau) xi (the MYULA move, :150); accepted with probability
- * min(1, pi(x') q(x|x') / (pi(x) q(x'|x))), pi = exp(-f - g), q(.|b) = N(m(b), 2 tau I) (:139-143,151-154); u ~ U(0,1) from
+ * min(1, pi(x') q(x|x') / (pi(x) q(x'|x))), pi = exp(-f - epsg*g), q(.|b) = N(m(b), 2 tau I) (:139-143,151-154); u ~ U(0,1) from
  * Philox (ctr = (0, iteration, global chain id, 0x4C4D4302), key = seed).  A rejected chain keeps its state, which is
  * counted again by the moment accumulators (the reference's toy version drops rejected iterations from its output list).
- * All lmc_sampler_* calls apply; n_chains <= 65535. */
+ * All lmc_sampler_* calls apply. */
 int lmc_mymala_create(const lmc_myula_config* cfg, lmc_sampler** out);
 /* accepted_dev [n_chains] uint64: accepted proposals so far; last_log_alpha_dev [n_chains] f64 (nullable): log acceptance
  * ratio of the latest iteration.  Device buffers. */
@@ -239,6 +265,27 @@ int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_lau
 /* name of the step kernel variant selected for this configuration (for profiles/) */
 const char* lmc_sampler_kernel_name(const lmc_sampler* s);
 
+/* ---- multi-GPU: the one collective of the path ----------------------------------------------
+ * Chains are sharded over GPUs by global chain id (chain_offset), one process per GPU, no data-path collective.  The only
+ * exchange is the sum of the posterior-moment accumulators over the ranks -- what generalises the `.mean(axis=0)` over iterates
+ * of prox_lmc_deconv.py:474 to a multi-GPU job.
+ *
+ * lmc_allreduce_moments: packs this sampler's {sum x [H][W], sum x^2 [H][W], count} into one float64 buffer, runs ONE
+ * ncclAllReduce(ncclSum) (RCCL over xGMI) on `stream`, writes the job-wide sums to sum_dev / sumsq_dev (device, [H][W] double,
+ * nullable), synchronises `stream` and returns the job-wide count.  The sampler's own accumulators are left untouched.
+ * rccl_comm: an ncclComm_t passed as void* -- from lmc_rccl_comm_create below or any communicator the host already has (e.g.
+ * torch.distributed's ProcessGroupNCCL) -- with one rank per sampler; NULL = a job of one rank (plain copy).
+ * librccl is dlopen'd on first use (LMC_RCCL_LIB overrides the search: librccl.so.1 already in the process, then the default
+ * paths); without it these calls return LMC_E_UNSUPPORTED and everything else works. */
+#define LMC_RCCL_UNIQUE_ID_BYTES 128
+int lmc_rccl_available(void);
+/* ncclGetUniqueId on one rank; the host distributes the 128 bytes to the others (MPI, a file, torch.distributed ...). */
+int lmc_rccl_unique_id(void* id128_host);
+/* ncclCommInitRank on the CURRENT device (one process per GPU).  Collective: every rank of the job calls it. */
+int lmc_rccl_comm_create(void** comm_out, int32_t world, int32_t rank, const void* id128_host);
+int lmc_rccl_comm_destroy(void* comm);
+int lmc_allreduce_moments(lmc_sampler* s, void* rccl_comm, double* sum_dev, double* sumsq_dev, uint64_t* count, void* stream);
+
 /* ---- ULPDA sampler (replaces algs.UnadjustedLangevinPrimalDual, algs.py:295-474) --------------------
  *   x    <- prox_{tau f}(x - tau (A^T y + z)) + sqrt(2 tau) xi      (algs.py:440/446)
  *   xhat <- x + theta (x - x_old)                                   (:441/447)
@@ -270,14 +317,16 @@ int lmc_sampler_get_dual(lmc_sampler* s, float* y_dev, void* stream);
 /* change (tau, mu) for the following iterations (the reference accepts per-iteration arrays, algs.py:402-408) */
 int lmc_sampler_set_steps(lmc_sampler* s, float tau, float mu);
 
-/* Relative residual |r| <= tol |b| at which the inner solver of the implicit data step (lmc_l2_prox, ULPDA) stops before
+/* Library-wide DEFAULT (used when lmc_problem.implicit_tol is 0; per-handle / per-call value: lmc_problem.implicit_tol) of the
+ * relative residual |r| <= tol |b| at which the inner solver of the implicit data step (lmc_l2_prox, ULPDA) stops before
  * cg_niter / niter iterations -- the stopping rule of the reference's solver (scipy lsqr's btol, default 1e-6, at algs.py:250).
  * Decided on the device for the whole batch of chains (all must satisfy it); tol = 0 disables it (always CG, all iterations).
  * Default 1e-6.  Returns the previous value; a negative argument only queries. */
 float lmc_set_cg_tolerance(float tol);
 
-/* Step-kernel variant used by lmc_sampler_step / lmc_fused_eval: 0 = auto (default), 1 = LDS-tiled,
- * 2 = streaming register pipeline (one wave group), 3 = the same pipeline split over two wave groups,
+/* Library-wide DEFAULT of the step-kernel variant, used by launches whose lmc_problem.step_variant is 0 (per-handle / per-call
+ * selection: lmc_problem.step_variant; this switch is process-global and not thread-safe -- A/B tests only): 0 = auto (default),
+ * 1 = LDS-tiled, 2 = (removed in ABI 2: the one-group streaming pipeline; LMC_E_INVALID), 3 = the row pipeline split over two wave groups,
  * 4 = HBM-bound tiled kernel for closed-form priors, 5 = register-block kernel (stencil-free data term, prox local to
  * 8 x 8 blocks: Haar-l1 / l2 / l1 / none; H, W multiples of 8), 6 = barrier-free row streaming (separable blur + closed-form
  * prior, W <= 512, W % 4 == 0), 7 = stage-parallel full-width TV pipeline (isotropic TV with 10, 20, ... 60 dual iterations, separable

@@ -13,14 +13,15 @@ from .algs import (MYULAResult, MYULASampler, MYMALASampler, MoreauYosidaUnadjus
 from . import diagnostics, metrics
 from .diagnostics import ChainTrace, chain_probes, ess, split_rhat
 from .metrics import MetricsCallback, mean_squared_error, peak_signal_noise_ratio, signal_noise_ratio
-from .sharding import allgather_chains, allreduce_moments, chain_shard, posterior_mean_var, sharded_myula
+from .sharding import (allgather_chains, allreduce_moments, allreduce_sampler_moments, chain_shard, posterior_mean_var, rccl_comm,
+                       sharded_myula)
 
 __all__ = [
     "diagnostics", "ChainTrace", "chain_probes", "ess", "split_rhat", "allgather_chains",
     "metrics", "MetricsCallback", "mean_squared_error", "peak_signal_noise_ratio", "signal_noise_ratio",
-    "allreduce_moments", "chain_shard", "posterior_mean_var", "sharded_myula",
+    "allreduce_moments", "allreduce_sampler_moments", "rccl_comm", "chain_shard", "posterior_mean_var", "sharded_myula",
     "LMCError", "Convolve2D", "Diagonal", "Gradient", "Identity", "LinearOperator",
     "L1", "L2", "L21", "TV", "L2_ncvx_tv", "WaveletL1", "ProxOperator", "fgp_betas",
     "MYULASampler", "MYMALASampler", "MoreauYosidaMetropolisAdjustedLangevin", "MYULAResult", "MoreauYosidaUnadjustedLangevin", "ULPDASampler", "UnadjustedLangevinPrimalDual", "mean_var_from_moments", "set_step_variant", "set_cg_tolerance",
 ]
-__version__ = "0.1.0"
+__version__ = "0.2.0"

@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblmc_atomi.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enums (include/lmc_atomi.h)
 DATA_NONE, DATA_IDENTITY, DATA_BLUR, DATA_MASK = 0, 1, 2, 3
@@ -52,6 +52,12 @@ class lmc_problem(C.Structure):
         ("ncvx_lambda", C.c_float),
         ("ncvx_gamma", C.c_float),
         ("ncvx_niter", C.c_int32),
+        # ABI 2
+        ("tv_lagged_output", C.c_int32),
+        ("tv_rtol", C.c_float),
+        ("step_variant", C.c_int32),
+        ("implicit_tol", C.c_float),
+        ("tv_warm", C.c_int32),
     ]
 
 
@@ -126,7 +132,14 @@ _SIGNATURES = {
     "lmc_sampler_set_dual": (C.c_int, [_P, _P, _P]),
     "lmc_sampler_get_dual": (C.c_int, [_P, _P, _P]),
     "lmc_sampler_set_steps": (C.c_int, [_P, C.c_float, C.c_float]),
+    "lmc_rccl_available": (C.c_int, []),
+    "lmc_rccl_unique_id": (C.c_int, [_P]),
+    "lmc_rccl_comm_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int32, _P]),
+    "lmc_rccl_comm_destroy": (C.c_int, [_P]),
+    "lmc_allreduce_moments": (C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_uint64), _P]),
 }
+RCCL_UNIQUE_ID_BYTES = 128
+VARIANTS = ["auto", "tile", "(removed)", "split", "point", "block", "rows", "pipe"]
 
 _lib = None
 _lock = threading.Lock()

@@ -19,12 +19,16 @@ def device(dev=None) -> torch.device:
     return torch.device(dev)
 
 
-def stream_ptr() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(dev=None) -> C.c_void_p:
+    """Current stream of ``dev`` (default: the current device) as a ``hipStream_t``."""
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def to_dev(x, dev=None) -> torch.Tensor:
-    """numpy / torch (any dtype, any device) -> contiguous fp32 tensor in HBM."""
+    """numpy / torch (any dtype, any device) -> contiguous fp32 tensor in HBM: on ``dev`` if given, else where a GPU tensor already
+    lives, else on the current device."""
+    if dev is None and isinstance(x, torch.Tensor) and x.is_cuda:
+        dev = x.device
     d = device(dev)
     if isinstance(x, torch.Tensor):
         return x.to(device=d, dtype=torch.float32).contiguous()
@@ -51,3 +55,9 @@ def fptr(a: np.ndarray):
 
 def lib():
     return _capi.load()
+
+
+def run(t: torch.Tensor, name: str, *args):
+    """Call the stateless entry point ``name(*args, stream)`` on the device ``t`` lives on, on that device's current stream."""
+    with torch.cuda.device(t.device):
+        _capi.check(getattr(lib(), name)(*args, stream_ptr()))

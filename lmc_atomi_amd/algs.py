@@ -50,14 +50,20 @@ class MYULASampler:
     """
 
     def __init__(self, proxf, proxg, dims, n_chains=1, tau=None, gamma=0.1, epsg=1.0, seed=0,
-                 chain_offset=0, noise="philox", moments=False, burn_in=0, thin=1, device=None):
+                 chain_offset=0, noise="philox", moments=False, burn_in=0, thin=1, device=None, variant=None, tv_warm=None):
+        """``variant``: step-kernel variant of THIS sampler ('auto' | 'tile' | 'split' | 'point' | 'block' | 'rows' | 'pipe'; None = the
+        library default, :func:`set_step_variant`).  ``tv_warm``: carry the TV dual between iterations (see :class:`TV`; None = as
+        ``proxg.warm`` says).  Every call on the sampler runs on ``device`` whatever the current device is."""
         if tau is None:
             raise NotImplementedError("tau=None (backtracking) is not implemented by the reference loop either")
         self.dims = (int(dims[0]), int(dims[1]))
         self.n_chains = int(n_chains)
         self.device = _dev.device(device)
         self.proxf, self.proxg = proxf, proxg
-        self._problem = _Problem(self.dims, _data_descriptor(proxf), _prior_descriptor(proxg), self.device)
+        opts = {"step_variant": variant or 0}
+        if tv_warm is not None:
+            opts["tv_warm"] = bool(tv_warm)
+        self._problem = _Problem(self.dims, _data_descriptor(proxf), _prior_descriptor(proxg), self.device, options=opts)
         cfg = _capi.lmc_myula_config()
         cfg.struct_size = C.sizeof(_capi.lmc_myula_config)
         cfg.problem = self._problem.c
@@ -103,13 +109,13 @@ class MYULASampler:
             xt = xt.reshape(1, *self.dims).expand(self.shape).contiguous()
         if xt.numel() != self.n_chains * n:
             raise ValueError(f"state of shape {tuple(xt.shape)} does not match {self.shape}")
-        _capi.check(_dev.lib().lmc_sampler_set_state(self._h, _dev.ptr(xt), _dev.stream_ptr()))
-        torch.cuda.current_stream().synchronize()  # xt may be a temporary
+        _capi.check(_dev.lib().lmc_sampler_set_state(self._h, _dev.ptr(xt), _dev.stream_ptr(self.device)))
+        torch.cuda.current_stream(self.device).synchronize()  # xt may be a temporary
 
     def get_state(self, out=None):
         if out is None:
             out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
-        _capi.check(_dev.lib().lmc_sampler_get_state(self._h, _dev.ptr(out), _dev.stream_ptr()))
+        _capi.check(_dev.lib().lmc_sampler_get_state(self._h, _dev.ptr(out), _dev.stream_ptr(self.device)))
         return out
 
     @property
@@ -129,9 +135,9 @@ class MYULASampler:
             nt = _dev.to_dev(noise, self.device)
             if nt.numel() != n_iters * self.n_chains * self.dims[0] * self.dims[1]:
                 raise ValueError("noise must have shape [n_iters, n_chains, H, W]")
-        _capi.check(_dev.lib().lmc_sampler_step(self._h, int(n_iters), _dev.ptr(nt), _dev.stream_ptr()))
+        _capi.check(_dev.lib().lmc_sampler_step(self._h, int(n_iters), _dev.ptr(nt), _dev.stream_ptr(self.device)))
         if nt is not None:
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream(self.device).synchronize()
 
     def enable_timing(self, on=True):
         """Bracket every step-kernel launch with a HIP event pair on the launch stream."""
@@ -152,12 +158,12 @@ class MYULASampler:
         """Per-chain ``f(x_c)``, ``g(x_c)`` (float64 tensors in HBM) -- the energy log of algs.py:578-582."""
         f = torch.empty(self.n_chains, dtype=torch.float64, device=self.device)
         g = torch.empty(self.n_chains, dtype=torch.float64, device=self.device)
-        _capi.check(_dev.lib().lmc_sampler_energies(self._h, _dev.ptr(f), _dev.ptr(g), _dev.stream_ptr()))
+        _capi.check(_dev.lib().lmc_sampler_energies(self._h, _dev.ptr(f), _dev.ptr(g), _dev.stream_ptr(self.device)))
         return f, g
 
     def noise_field(self, iteration):
         out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
-        _capi.check(_dev.lib().lmc_sampler_noise(self._h, int(iteration), _dev.ptr(out), _dev.stream_ptr()))
+        _capi.check(_dev.lib().lmc_sampler_noise(self._h, int(iteration), _dev.ptr(out), _dev.stream_ptr(self.device)))
         return out
 
     def moments(self):
@@ -166,11 +172,22 @@ class MYULASampler:
         s2 = torch.empty(self.dims, dtype=torch.float64, device=self.device)
         cnt = C.c_uint64()
         _capi.check(_dev.lib().lmc_sampler_get_moments(self._h, _dev.ptr(s1), _dev.ptr(s2), C.byref(cnt),
-                                                       _dev.stream_ptr()))
+                                                       _dev.stream_ptr(self.device)))
         return s1, s2, int(cnt.value)
 
     def reset_moments(self):
-        _capi.check(_dev.lib().lmc_sampler_reset_moments(self._h, _dev.stream_ptr()))
+        _capi.check(_dev.lib().lmc_sampler_reset_moments(self._h, _dev.stream_ptr(self.device)))
+
+    def allreduce_moments(self, rccl_comm):
+        """Job-wide (sum, sumsq, count): ONE ``ncclAllReduce`` (RCCL over xGMI) of the packed accumulators through the C ABI
+        (``lmc_allreduce_moments``).  ``rccl_comm``: an ``ncclComm_t`` as an integer / ``c_void_p`` (``None`` or 0 = a job of one rank)."""
+        s1 = torch.empty(self.dims, dtype=torch.float64, device=self.device)
+        s2 = torch.empty(self.dims, dtype=torch.float64, device=self.device)
+        cnt = C.c_uint64()
+        comm = rccl_comm if isinstance(rccl_comm, C.c_void_p) else C.c_void_p(int(rccl_comm or 0))
+        _capi.check(_dev.lib().lmc_allreduce_moments(self._h, comm, _dev.ptr(s1), _dev.ptr(s2), C.byref(cnt),
+                                                     _dev.stream_ptr(self.device)))
+        return s1, s2, int(cnt.value)
 
 
 class ULPDASampler(MYULASampler):
@@ -179,7 +196,7 @@ class ULPDASampler(MYULASampler):
     gradient.  The implicit data step runs ``proxf.niter`` warm-started CG iterations per chain on the GPU."""
 
     def __init__(self, proxf, proxg, A, dims, n_chains=1, tau=None, mu=None, theta=1.0, gfirst=True, z=None, seed=0,
-                 chain_offset=0, noise="philox", moments=False, burn_in=0, thin=1, device=None):
+                 chain_offset=0, noise="philox", moments=False, burn_in=0, thin=1, device=None, variant=None, implicit_tol=None):
         from .operators import Gradient
         from .proximal import L1, L21
         if not isinstance(A, Gradient):
@@ -194,7 +211,11 @@ class ULPDASampler(MYULASampler):
         self.n_chains = int(n_chains)
         self.device = _dev.device(device)
         self.proxf, self.proxg = proxf, proxg
-        self._problem = _Problem(self.dims, _data_descriptor(proxf), prior, self.device)
+        # implicit_tol: relative residual of THIS sampler's implicit data step (None = the library default, set_cg_tolerance;
+        # 0 or negative = disabled: always all iterations)
+        tol = 0.0 if implicit_tol is None else (float(implicit_tol) if implicit_tol > 0 else -1.0)
+        self._problem = _Problem(self.dims, _data_descriptor(proxf), prior, self.device,
+                                 options={"step_variant": variant or 0, "implicit_tol": tol})
         cfg = _capi.lmc_ulpda_config()
         cfg.struct_size = C.sizeof(_capi.lmc_ulpda_config)
         cfg.problem = self._problem.c
@@ -229,12 +250,12 @@ class ULPDASampler(MYULASampler):
             yt = yt.reshape(1, n2).expand(self.n_chains, n2).contiguous()
         if yt.numel() != self.n_chains * n2:
             raise ValueError("dual state must have 2*H*W entries per chain")
-        _capi.check(_dev.lib().lmc_sampler_set_dual(self._h, _dev.ptr(yt), _dev.stream_ptr()))
-        torch.cuda.current_stream().synchronize()
+        _capi.check(_dev.lib().lmc_sampler_set_dual(self._h, _dev.ptr(yt), _dev.stream_ptr(self.device)))
+        torch.cuda.current_stream(self.device).synchronize()
 
     def get_dual(self):
         out = torch.empty((self.n_chains, 2) + self.dims, dtype=torch.float32, device=self.device)
-        _capi.check(_dev.lib().lmc_sampler_get_dual(self._h, _dev.ptr(out), _dev.stream_ptr()))
+        _capi.check(_dev.lib().lmc_sampler_get_dual(self._h, _dev.ptr(out), _dev.stream_ptr(self.device)))
         return out
 
 
@@ -454,7 +475,7 @@ class MYMALASampler(MYULASampler):
         """(accepted proposals per chain [C] int64 tensor, log acceptance ratio of the last iteration [C] float64 tensor)."""
         acc = torch.empty(self.n_chains, dtype=torch.int64, device=self.device)
         la = torch.empty(self.n_chains, dtype=torch.float64, device=self.device)
-        _capi.check(_dev.lib().lmc_sampler_get_acceptance(self._h, _dev.ptr(acc), _dev.ptr(la), _dev.stream_ptr()))
+        _capi.check(_dev.lib().lmc_sampler_get_acceptance(self._h, _dev.ptr(acc), _dev.ptr(la), _dev.stream_ptr(self.device)))
         return acc, la
 
     def acceptance_rate(self):
@@ -503,9 +524,11 @@ def set_cg_tolerance(tol=1e-6):
 
 
 def set_step_variant(variant="auto"):
-    """Select the step-kernel variant ('auto' | 'tile' | 'stream' | 'split' | 'point' | 'block' | 'rows' | 'pipe'); returns the previous one.
-    All compute the same update -- for A/B tests and profiles."""
-    names = ["auto", "tile", "stream", "split", "point", "block", "rows", "pipe"]
+    """Library-wide DEFAULT of the step-kernel variant ('auto' | 'tile' | 'split' | 'point' | 'block' | 'rows' | 'pipe'); returns the previous
+    one.  Process-global, for A/B tests and profiles; a sampler's own ``variant=`` argument takes precedence.  All compute the same update."""
+    names = _capi.VARIANTS
+    if variant not in names or variant.startswith("("):
+        raise ValueError(f"unknown step-kernel variant {variant!r} (the one-group 'stream' kernel of ABI 1 was removed)")
     prev = _dev.lib().lmc_set_step_variant(names.index(variant))
     if prev < 0:
         _capi.check(prev)

@@ -50,6 +50,8 @@ struct StepArgs {
   const float* tv_in;        // NULL: start from zero
   float* tv_out;             // NULL: do not store
   int tv_state_only;         // != 0: store the state and skip the combine / x_out (non-final chunk)
+  int tv_warm;               // pipe kernel: tv_in / tv_out are [C][2][H][W] = the projected dual (p, q) carried from one MYULA
+                             // iteration to the next (warm-started TV prox, momentum restarted) instead of the 4-field link state
   // extra gradient term g += extra_coef * (x - extra[c][i][j])   (ME-TV: extra = prox_{gamma TV}(x), algs.py:282)
   const float* extra;
   float extra_coef;

@@ -42,9 +42,6 @@ hipError_t launch_noise(float* out, int C, int H, int W, uint32_t key0, uint32_t
 }  // namespace lmc
 
 namespace lmc {
-// streaming register-pipeline variant (lmc_step_stream.hip)
-bool stream_supported(const StepArgs& a);
-hipError_t launch_step_stream(StepArgs a, hipStream_t st);
 // HBM-bound tiled kernel for closed-form priors (lmc_step_point.hip)
 bool point_supported(const StepArgs& a);
 hipError_t launch_step_point(StepArgs a, hipStream_t st);
@@ -61,6 +58,9 @@ int centred_blur_taps(const BlurTaps& T, float* uc, float* vc);
 bool pipe_supported(const StepArgs& a);                  // one launch covers it (10 dual iterations)
 int pipe_links(const StepArgs& a);                       // launches needed (20 .. 60 iterations: chained through HBM state), 0 = not covered
 hipError_t launch_step_pipe(StepArgs a, hipStream_t st, float* state0 = nullptr, float* state1 = nullptr);
+// warm-started TV prox: a.tv_in / a.tv_out = [C][2][H][W] projected dual of the previous / this MYULA iteration
+bool pipe_warm_supported(const StepArgs& a);
+hipError_t launch_step_pipe_warm(StepArgs a, hipStream_t st);
 // split streaming variant: the same pipeline over two wave groups (lmc_step_split.hip)
 bool split_supported(const StepArgs& a);
 hipError_t launch_step_split(StepArgs a, hipStream_t st);
@@ -89,8 +89,6 @@ hipError_t cg_dir(float* p, const float* r, int64_t C, size_t img, double* rs, c
 hipError_t cheb_count(int64_t C, const double* stat, double inv_alpha2, double tol, double inv_log_inv_c, int kmax, int* count,
                       hipStream_t st);
 hipError_t cg_check(int64_t C, const double* rsv, const double* b2, double tol2, int* done, hipStream_t st);
-hipError_t ulpda_cg_solve(float* u, const float* rhs, float* r, float* p, float* q, float* tmp, double* scal, int64_t C, int H,
-                          int W, const BlurTaps& T, float ts, int niter, hipStream_t st);
 }  // namespace lmc
 
 namespace lmc {
@@ -98,7 +96,7 @@ namespace lmc {
 hipError_t mala_propose(const float* mx, const float* xi, float* xp, int64_t C, size_t img, float s, double* d1, hipStream_t st);
 hipError_t mala_propose_philox(const float* mx, float* xp, int64_t C, int H, int W, float s, uint32_t key0, uint32_t key1,
                                uint32_t iteration, uint32_t chain_offset, double* d1, hipStream_t st);
-hipError_t mala_accept(int C, double* U, const double* fp, const double* gp, const double* d1, const double* d2, float tau,
+hipError_t mala_accept(int C, double* U, const double* fp, const double* gp, float epsg, const double* d1, const double* d2, float tau,
                        uint32_t key0, uint32_t key1, uint32_t iteration, uint32_t chain_offset, int* flag,
                        unsigned long long* nacc, double* log_alpha, hipStream_t st);
 hipError_t mala_select(const int* flag, float* x, float* mx, const float* xp, const float* mxp, int64_t C, size_t img, int when,

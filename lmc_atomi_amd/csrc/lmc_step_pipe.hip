@@ -1,715 +1,95 @@
-// Fused MYULA update with the isotropic-TV prox (K FGP dual iterations), "pipe" variant:
-//     out = a*x - t*sigma_f H^T(Hx - y) + b*prox_{gamma TV}(x) + s*xi                      (algs.py:569)
-//
-// Same row pipeline as lmc_step_split.hip (stage k runs on row t-E-2k, one barrier per tick) but laid out the other way
-// round: a wavefront owns the FULL WIDTH of the image (lane = PXL consecutive pixels, W <= 64*PXL) and the pipeline STAGES
-// are spread over the wavefronts of the workgroup:
-//   wave 0      "L": HBM load of row t -> x ring (LDS); blur-gradient pipeline on the ring, one row ahead of the output
-//   wave 1..NT  "T": two TV stages each (2j-1, 2j); stage outputs handed to the next wave through LDS (parity double
-//                    buffer, read one tick later -- the latency a stage boundary has anyway)
-//   wave NT+1   "C": final primal step x - gamma div(rr^K, ss^K), combine, HBM store
-//   wave NT+2   "N": Philox normals of the next quad row-group into an LDS slab (read by C four ticks later)
-// Because a wave spans the image width, horizontal neighbours are in the same lane (7 of 8) or one wave-shift DPP move
-// away (2 per stage per PXL pixels): no row-edge ghost exchange, no per-pixel DPP.  One workgroup = one chain.
-#include "lmc_device.h"
-#include "lmc_launch.h"
+// Host side of the "pipe" step kernel (lmc_step_pipe_kernel.h): coverage tests, dispatch, chained launches.  This translation unit
+// holds the instantiations WITHOUT dual-state hand-over (one launch = the whole TV prox from the zero dual state); the ones that
+// read / write the dual state in HBM (chained launches, warm-started prox) are in lmc_step_pipe_chain.hip.
+#include "lmc_step_pipe_kernel.h"
 
 namespace lmc {
 
-#ifdef LMC_EXP_NOBARRIER   // timing experiment: waves free-run (results are wrong)
-#define PIPE_TICK_SYNC() do {} while (0)
-#else
-#define PIPE_TICK_SYNC() __syncthreads()
-#endif
-
-template <int K>
-struct PipeGeom {
-  static constexpr int D = (2 * K + 2 > 10) ? 2 * K + 2 : 10;   // output row lag: o = t - D
-  static constexpr int E = D - (2 * K + 2);                     // extra lag of the TV pipeline
-  static constexpr int RB = D + 1;                              // x ring rows: t-D .. t
-  static constexpr int NT = K / 2;                              // TV waves (two stages each)
-};
-
-template <int K, int PXL, bool CHAIN = false>
-struct PipeLds {
-  static constexpr int BW = 64 * PXL;
-  static constexpr int o_x = 0;                                        // [RB][BW]
-  static constexpr int o_hand = o_x + PipeGeom<K>::RB * BW;            // [NT][2][4][BW]: rr, ss, p, q of the wave's last stage
-  // chained launches (more than K dual iterations): the last boundary (T_NT -> C) carries rr, ss only, [2][2][BW], and the 8*BW
-  // saved hold the dual state of the previous launch for stage 1, [2][4][BW] (LDS budget: 160 KB)
-  static constexpr int o_hand_last = o_hand + (PipeGeom<K>::NT - 1) * 8 * BW;
-  static constexpr int o_hand0 = o_hand_last + 4 * BW;
-  static constexpr int o_g = CHAIN ? o_hand0 + 8 * BW : o_hand + PipeGeom<K>::NT * 2 * 4 * BW;    // [2][BW] gradient of the output row
-  static constexpr int o_slab = o_g + 2 * BW;                          // [2][4][PXL][64] normals of this and the next quad row-group
-  static constexpr int total = o_slab + 2 * 4 * PXL * 64;
-};
-
-// LDS rows are stored so that every 16-byte access of a wave is contiguous: pixel k of lane l at (k>>2)*256 + 4*l + (k&3).
-template <int PXL>
-__device__ __forceinline__ void prow_load(float (&v)[PXL], const float* row, int lane) {
-#pragma unroll
-  for (int g = 0; g < PXL / 4; ++g) {
-    const float4 q = *reinterpret_cast<const float4*>(row + g * 256 + lane * 4);
-    v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
-  }
-}
-template <int PXL>
-__device__ __forceinline__ void prow_store(float* row, int lane, const float (&v)[PXL]) {
-#pragma unroll
-  for (int g = 0; g < PXL / 4; ++g)
-    *reinterpret_cast<float4*>(row + g * 256 + lane * 4) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-}
-
-// Packed fp32: gfx950 issues one wave64 VALU instruction per 4 cycles per SIMD, and v_pk_fma/mul/add_f32 process two floats
-// per lane in that slot.  The TV stages therefore work on pixel PAIRS (2i, 2i+1) held in even-aligned register pairs; only
-// the two neighbour-shifted operands of a stage need a v_pk_mov to re-pair, max / rsq stay scalar.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f pk_set(float a) { return v2f{a, a}; }
-
-template <int NP>   // NP = PXL / 2 pairs
-__device__ __forceinline__ void pairs_load(v2f (&v)[NP], const float* row, int lane) {
-#pragma unroll
-  for (int g = 0; g < NP / 2; ++g) {
-    const float4 q = *reinterpret_cast<const float4*>(row + g * 256 + lane * 4);
-    v[2 * g] = v2f{q.x, q.y};
-    v[2 * g + 1] = v2f{q.z, q.w};
-  }
-}
-template <int NP>
-__device__ __forceinline__ void pairs_store(float* row, int lane, const v2f (&v)[NP]) {
-#pragma unroll
-  for (int g = 0; g < NP / 2; ++g)
-    *reinterpret_cast<float4*>(row + g * 256 + lane * 4) = make_float4(v[2 * g].x, v[2 * g].y, v[2 * g + 1].x, v[2 * g + 1].y);
-}
-
-template <int NP>
-struct DualRow { v2f rr[NP], ss[NP], p[NP], q[NP]; };
-
-// One FGP dual iteration on NP pixel pairs per lane.  r1, s1 = (rr, ss)^{k-1} on row a; in0 = (rr, ss, p, q)^{k-1} on row
-// b = a-1; solb = sol^k on row b (in) -> sol^k on row a (out); out = (rr, ss, p, q)^k on row b.
-template <int NP>
-__device__ __forceinline__ void pipe_stage(const v2f (&xa)[NP], const v2f (&r1)[NP], const v2f (&s1)[NP], const DualRow<NP>& in0,
-                                           v2f (&solb)[NP], float gam, float cdown, float cstep, float cr_last, float beta,
-                                           DualRow<NP>& out) {
-  v2f sol[NP];
-  const float ssl0 = dpp_left0(s1[NP - 1].y);
-  const v2f ngam = pk_set(-gam), ncd = pk_set(-cdown), vb = pk_set(beta);
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const v2f ssl = v2f{i == 0 ? ssl0 : s1[i - 1].y, s1[i].x};
-    sol[i] = pk_fma(ngam, (r1[i] - in0.rr[i]) + (s1[i] - ssl), xa[i]);
-  }
-  const float solr_last = dpp_right0(solb[0].x);
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const v2f solr = v2f{solb[i].y, i == NP - 1 ? solr_last : solb[i + 1].x};
-    const v2f ncr = i == NP - 1 ? v2f{-cstep, -cr_last} : pk_set(-cstep);
-    const v2f r = pk_fma(ncd, sol[i] - solb[i], in0.rr[i]);
-    const v2f s = pk_fma(ncr, solr - solb[i], in0.ss[i]);
-    const v2f n2 = pk_fma(r, r, s * s);
-    // min(1, rsq(n2)) == rsq(max(n2, 1)) bit for bit (rsq is monotone, rsq(1) = 1); written as a [0,1] clamp it folds into the
-    // output modifier of v_rsq_f32 and the v_max disappears
-    const v2f inv = v2f{__builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(n2.x), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(n2.y), 0.f, 1.f)};
-    const v2f pn = r * inv, qn = s * inv;
-    out.rr[i] = pk_fma(vb, pn - in0.p[i], pn);
-    out.ss[i] = pk_fma(vb, qn - in0.q[i], qn);
-    out.p[i] = pn;
-    out.q[i] = qn;
-  }
-#pragma unroll
-  for (int i = 0; i < NP; ++i) solb[i] = sol[i];
-}
-
-// Stage 1 of a launch that starts from the zero dual state: (rr, ss, p, q)^0 = 0, so sol^1 = x and the differences with the previous
-// iterate vanish.  Bit-identical to pipe_stage() fed with zeros (x - 0 = x, fma(c, d, 0) = c*d), at ~60 % of its instructions.
-template <int NP>
-__device__ __forceinline__ void pipe_stage_first(const v2f (&xa)[NP], v2f (&solb)[NP], float cdown, float cstep, float cr_last, float beta,
-                                                 DualRow<NP>& out) {
-  const float solr_last = dpp_right0(solb[0].x);
-  const v2f ncd = pk_set(-cdown), vb = pk_set(beta);
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const v2f solr = v2f{solb[i].y, i == NP - 1 ? solr_last : solb[i + 1].x};
-    const v2f ncr = i == NP - 1 ? v2f{-cstep, -cr_last} : pk_set(-cstep);
-    const v2f r = ncd * (xa[i] - solb[i]);
-    const v2f s = ncr * (solr - solb[i]);
-    const v2f n2 = pk_fma(r, r, s * s);
-    const v2f inv = v2f{__builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(n2.x), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(n2.y), 0.f, 1.f)};
-    const v2f pn = r * inv, qn = s * inv;
-    out.rr[i] = pk_fma(vb, pn, pn);
-    out.ss[i] = pk_fma(vb, qn, qn);
-    out.p[i] = pn;
-    out.q[i] = qn;
-  }
-#pragma unroll
-  for (int i = 0; i < NP; ++i) solb[i] = xa[i];
-}
-
-// Row load with zero fill.  The load itself is unconditional (masked-off lanes read the start of the row, always a valid address:
-// callers pass a clamped row) and the mask is applied to the value: a predicated load costs an exec-mask branch per access and
-// splits the tick into basic blocks the scheduler cannot move loads across.
-template <int PXL>
-__device__ __forceinline__ void gload_row(float (&dst)[PXL], const float* __restrict__ row, int c0, int W, bool ok) {
-#pragma unroll
-  for (int g = 0; g < PXL / 4; ++g) {
-    const bool okg = ok && c0 + 4 * g < W;
-    const float4 v = *reinterpret_cast<const float4*>(row + (okg ? c0 + 4 * g : 0));
-    dst[4 * g] = okg ? v.x : 0.f; dst[4 * g + 1] = okg ? v.y : 0.f; dst[4 * g + 2] = okg ? v.z : 0.f; dst[4 * g + 3] = okg ? v.w : 0.f;
-  }
-}
-
-// The same without the select: for values that are masked where they are USED (a select at load time makes the wave wait for
-// the prefetch at once).  Lanes past the row read its start.
-template <int PXL>
-__device__ __forceinline__ void gload_raw(float (&dst)[PXL], const float* __restrict__ row, int c0, int W) {
-#pragma unroll
-  for (int g = 0; g < PXL / 4; ++g) {
-    const float4 v = *reinterpret_cast<const float4*>(row + (c0 + 4 * g < W ? c0 + 4 * g : 0));
-    dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
-  }
-}
-
-// KT = 0: no data term (pure prox, or t = 0).  CHAIN: the launch is one link of a chain of launches that together run more than K
-// dual iterations: stage 1 starts from the dual state A.tv_in of the previous link ([C][4][H][W]: rr, ss, p, q; NULL = zeros), the last
-// stage's state goes to A.tv_out (NULL = not stored), and with A.tv_state_only the combine / store of x_out is skipped.
-template <int K, int PXL, int KT, bool CHAIN = false>
-__global__ __launch_bounds__(64 * (K / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void myula_step_pipe_kernel(const StepArgs A) {
-  using G = PipeGeom<K>;
-  using L = PipeLds<K, PXL, CHAIN>;
-  constexpr int D = G::D, E = G::E, RB = G::RB, NT = G::NT, BW = L::BW, HW = KT > 0 ? (KT - 1) / 2 : 0;
-  static_assert(K >= 2 && K % 2 == 0, "two stages per TV wave");
-  static_assert(D >= KT + 1, "the blur pipeline reads ring rows at least one tick old");
-  extern __shared__ float lds[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int chain = blockIdx.x;
-  const int H = A.H, W = A.W;
-  const int c0 = lane * PXL;
-  const size_t img = (size_t)H * W;
-  const float* __restrict__ xin = A.x_in + (size_t)chain * img;
-  float* __restrict__ xout = A.x_out + (size_t)chain * img;
-
-  for (int e = threadIdx.x; e < L::o_slab; e += blockDim.x) lds[e] = 0.f;   // ring rows < 0, hand-offs of tick -1, g
-  __syncthreads();
-
-  const int T_end = (H + D + 3) & ~3;          // ticks, rounded up to the unroll factor (extra ticks write nothing)
-  float* const xring = lds + L::o_x;
-  auto ring_row = [&](int row) -> float* { return xring + ((unsigned)(row + RB) % (unsigned)RB) * BW; };   // row >= -RB
-
-#ifdef LMC_EXP_SKIP   // timing experiment (with LMC_EXP_NOBARRIER): the waves in the bitmask leave at once (results are wrong)
-  if ((LMC_EXP_SKIP >> wave) & 1) return;
-#endif
-  // Issue arbitration on the shared SIMDs: the short, latency-bound waves everybody waits for at the barrier (L publishes the
-  // ring row, C frees the hand-off slot) go first, the TV waves next, the Philox wave -- pure arithmetic, a quad row-group ahead
-  // of its consumer -- last.  Measured: 2.04 -> 1.98 ms; the other way round (TV waves first) 2.37 ms.
-#ifndef LMC_PRIO_L
-#define LMC_PRIO_L 3
-#define LMC_PRIO_C 3
-#define LMC_PRIO_T 1
-#define LMC_PRIO_N 0
-#endif
-  if (wave == 0) __builtin_amdgcn_s_setprio(LMC_PRIO_L);
-  else if (wave == NT + 1) __builtin_amdgcn_s_setprio(LMC_PRIO_C);
-  else if (wave <= NT) __builtin_amdgcn_s_setprio(LMC_PRIO_T);
-  else __builtin_amdgcn_s_setprio(LMC_PRIO_N);
-  if (wave == 0) {
-    // ---------------- L: loader + blur gradient -------------------------------------------------------------
-    const float* __restrict__ uv = A.blur.h;   // centred taps: u[0..KT) then v[0..KT) at h[kMaxBlur..]
-    // the windows of the last KT-1 horizontally filtered rows: with KT = 5 they are rings indexed by (tick & 3), static under the
-    // x4 unroll (row i-a in slot (U-a)&3, the new row replaces the oldest); otherwise they are rotated by moves
-    constexpr bool kRing4 = (KT == 5);
-    constexpr int NWIN = KT > 1 ? KT - 1 : 1;
-    // x rows: fetched kXPF ticks ahead, slot (tick & 3) (8 ahead was measured: no gain, +50 VGPRs)
-    constexpr int kXPF = 4;
-    float xpre[kXPF][PXL], hxw[NWIN][PXL], hrw[NWIN][PXL], ypre[4][PXL];   // y rows: fetched kYPF ticks ahead, slot (tick & 3)
-    constexpr int kYPF = KT == 7 ? 2 : 3;     // 7 taps: the windows already take 96 registers
-#pragma unroll
-    for (int a = 0; a < NWIN; ++a)
-#pragma unroll
-      for (int k = 0; k < PXL; ++k) { hxw[a][k] = 0.f; hrw[a][k] = 0.f; }
-#pragma unroll
-    for (int u = 0; u < kXPF; ++u) gload_raw<PXL>(xpre[u], xin + (size_t)min(u, H - 1) * W, c0, W);
-    // Vector-memory loads return in order: waiting for a load also waits for every load issued before it.  So the loads a tick
-    // consumes must be the OLDEST in flight: y rows are requested three ticks ahead and, inside a tick, before the x row that is only
-    // needed four ticks later (with y one tick ahead and issued after x, every tick waited for a fresh HBM access: ~2000 cycles).
-    if constexpr (KT > 0) {   // observation rows of the first kYPF residual rows
-#pragma unroll
-      for (int u = 0; u < kYPF; ++u) {
-        const int r = u + 1 - D + (KT - 1) - HW;
-        gload_raw<PXL>(ypre[u], A.y + (size_t)min(max(r, 0), H - 1) * W, c0, W);
-      }
-    }
-    // Without a blur: pointwise data terms (identity, diagonal mask).  Their gradient sigma_f m (m x - y) of row t + 1 - D -- the row the
-    // combine wave emits next tick -- is formed HERE (this wave issues no stores, so its loads never queue behind stores in vmcnt) from
-    // the ring copy of x and the observation / mask rows requested kYPF ticks ahead, and handed over through the same o_g slots as the
-    // blur gradient.
-    const bool pw_id = KT == 0 && A.data_kind == LMC_DATA_IDENTITY, pw_mask = KT == 0 && A.data_kind == LMC_DATA_MASK;
-    float mpre[KT == 0 ? 4 : 1][KT == 0 ? PXL : 1];
-    if constexpr (KT == 0) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) { ypre[u][k] = 0.f; mpre[u][k] = 0.f; }
-      if (pw_id || pw_mask) {
-#pragma unroll
-        for (int u = 0; u < kYPF; ++u) {
-          const size_t ro = (size_t)min(max(u + 1 - D, 0), H - 1) * W;
-          gload_raw<PXL>(ypre[u], A.y + ro, c0, W);
-          if (pw_mask) gload_raw<PXL>(mpre[u], A.mask + ro, c0, W);
-        }
-      }
-    }
-    // chained launch: the dual state rows for stage 1, fetched two ticks ahead (row t - E - 1 is published at tick t)
-    float spre[CHAIN ? 2 : 1][CHAIN ? 4 : 1][CHAIN ? PXL : 1];
-    const float* const sin = CHAIN && A.tv_in ? A.tv_in + (size_t)chain * 4 * img : nullptr;
-    if constexpr (CHAIN) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int rs = u - E - 1;
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-          gload_row<PXL>(spre[u][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H);
-      }
-    }
-    double facc = 0.0;        // sum of squared residuals (A.f_out)
-    auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
-      constexpr int U = decltype(uu)::value, P = U & 1;
-      if constexpr (KT > 0) {   // observation row of the residual row kYPF ticks from now
-        const int r3 = t + kYPF + 1 - D + (KT - 1) - HW;
-        gload_raw<PXL>(ypre[(U + kYPF) & 3], A.y + (size_t)min(max(r3, 0), H - 1) * W, c0, W);
-      } else if (pw_id || pw_mask) {
-        const size_t ro = (size_t)min(max(t + kYPF + 1 - D, 0), H - 1) * W;
-        gload_raw<PXL>(ypre[(U + kYPF) & 3], A.y + ro, c0, W);
-        if (pw_mask) gload_raw<PXL>(mpre[(U + kYPF) & 3], A.mask + ro, c0, W);
-      }
-      {   // row t arrives: publish it in the ring (zeros below the image); fetch row t + 4
-        float xv[PXL];
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) xv[k] = (t < H && c0 + (k & ~3) < W) ? xpre[U][k] : 0.f;
-        prow_store<PXL>(ring_row(t), lane, xv);
-        gload_raw<PXL>(xpre[U], xin + (size_t)min(t + kXPF, H - 1) * W, c0, W);
-      }
-      if constexpr (CHAIN) {   // dual state row t - E - 1 of the previous link -> stage 1's hand-off slot P (read next tick)
-        float* hb = lds + L::o_hand0 + P * 4 * BW;
-#pragma unroll
-        for (int f = 0; f < 4; ++f) prow_store<PXL>(hb + f * BW, lane, spre[P][f]);
-        const int rs = t + 2 - E - 1;
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-          gload_row<PXL>(spre[P][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H);
-      }
-      if constexpr (KT > 0) {
-      const int i = t + 1 - D + (KT - 1);       // blur input row (<= t-1: published in an earlier tick)
-      float hxn[PXL];
-      {
-        float xi[PXL], e[PXL + 2 * HW];
-        prow_load<PXL>(xi, ring_row(i), lane);
-#pragma unroll
-        for (int m = 0; m < HW; ++m) e[m] = dpp_left0(xi[PXL - HW + m]);
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) e[HW + k] = xi[k];
-#pragma unroll
-        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_right0(xi[m]);
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) {
-          float acc = uv[kMaxBlur] * e[k + 2 * HW];
-#pragma unroll
-          for (int b = 1; b < KT; ++b) acc = fmaf(uv[kMaxBlur + b], e[k + 2 * HW - b], acc);
-          hxn[k] = acc;
-        }
-      }
-      const int r = i - HW;                     // residual row: Hx[r] = sum_a u[a] hx[i - a]
-      float R[PXL];
-      {
-        const bool rowok = r >= 0 && r < H;
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) {
-          float acc = uv[0] * hxn[k];
-#pragma unroll
-          for (int a = 1; a < KT; ++a) acc = fmaf(uv[a], hxw[kRing4 ? ((U - a) & 3) : a - 1][k], acc);
-          R[k] = (rowok && c0 + (k & ~3) < W) ? acc - ypre[U & 3][k] : 0.f;
-        }
-        if (A.f_out) {
-#pragma unroll
-          for (int k = 0; k < PXL; ++k) facc = fma((double)R[k], (double)R[k], facc);
-        }
-        if constexpr (!kRing4) {
-#pragma unroll
-          for (int a = KT - 2; a >= 1; --a)
-#pragma unroll
-            for (int k = 0; k < PXL; ++k) hxw[a][k] = hxw[a - 1][k];
-        }
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) hxw[kRing4 ? (U & 3) : 0][k] = hxn[k];
-      }
-      {   // horizontal adjoint, then G[r - HW] = sum_a u[a] hR[r - 2HW + a]
-        float e[PXL + 2 * HW], gout[PXL];
-#pragma unroll
-        for (int m = 0; m < HW; ++m) e[m] = dpp_left0(R[PXL - HW + m]);
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) e[HW + k] = R[k];
-#pragma unroll
-        for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_right0(R[m]);
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) {
-          float hrn = uv[kMaxBlur] * e[k];
-#pragma unroll
-          for (int b = 1; b < KT; ++b) hrn = fmaf(uv[kMaxBlur + b], e[k + b], hrn);
-          float acc = uv[KT - 1] * hrn;
-#pragma unroll
-          for (int a = 0; a < KT - 1; ++a) acc = fmaf(uv[a], hrw[kRing4 ? ((U - (KT - 1 - a)) & 3) : KT - 2 - a][k], acc);
-          if constexpr (!kRing4) {
-#pragma unroll
-            for (int a = KT - 2; a >= 1; --a) hrw[a][k] = hrw[a - 1][k];
-          }
-          hrw[kRing4 ? (U & 3) : 0][k] = hrn;
-          gout[k] = A.sigma_f * acc;
-        }
-        prow_store<PXL>(lds + L::o_g + P * BW, lane, gout);      // row t + 1 - D, read by C next tick
-      }
-      }   // KT > 0
-      if constexpr (KT == 0) {
-        if (pw_id || pw_mask) {
-          const int i = t + 1 - D;                // <= t - 1: published in an earlier tick
-          float xi[PXL], gout[PXL];
-          prow_load<PXL>(xi, ring_row(i), lane);
-          const bool rowok = i >= 0 && i < H;
-#pragma unroll
-          for (int k = 0; k < PXL; ++k) {
-            float g = 0.f;
-            if (rowok && c0 + (k & ~3) < W) {
-              if (pw_id) g = A.sigma_f * (xi[k] - ypre[U & 3][k]);
-              else g = A.sigma_f * mpre[U & 3][k] * fmaf(mpre[U & 3][k], xi[k], -ypre[U & 3][k]);
-            }
-            gout[k] = g;
-          }
-          prow_store<PXL>(lds + L::o_g + P * BW, lane, gout);      // row t + 1 - D, read by C next tick
-        }
-      }
-      PIPE_TICK_SYNC();
-    };
-    for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
-    if (A.f_out) {
-      const double tot = wave_sum(facc);
-      if (lane == 0) unsafeAtomicAdd(&A.f_out[chain], 0.5 * (double)A.sigma_f * tot);
-    }
-  } else if (wave <= NT) {
-    // ---------------- T: TV stages k1 = 2*wave - 1 and k2 = 2*wave -----------------------------------------
-    // Wave 1 of a launch that starts from the zero dual state runs a specialised stage 1 (its own copy of the loop, no branch inside):
-    // it shares a SIMD with wave 5, and two full T waves on one SIMD are what bounds the tick.
-    auto t_role = [&](auto first_tag) __attribute__((always_inline)) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    const int k1 = 2 * wave - 1, k2 = 2 * wave;
-    const float gam = A.tv.gamma, cstep = A.tv.c;
-    const float beta1 = A.tv.betas[k1 - 1], beta2 = A.tv.betas[k2 - 1];
-    const float cr_last = (c0 + PXL - 1 == W - 1) ? 0.f : cstep;     // no horizontal difference across column W-1
-    float* const hout = lds + L::o_hand + (wave - 1) * 8 * BW;       // this wave's hand-off [2][4][BW] ([2][2][BW] for the last one if CHAIN)
-    const bool from_state = CHAIN && wave == 1 && A.tv_in != nullptr;
-    const float* const hin = from_state ? lds + L::o_hand0 : hout - 8 * BW;   // the previous wave's / the previous link's state
-    float* const sout = CHAIN && wave == NT && A.tv_out ? A.tv_out + (size_t)chain * 4 * img : nullptr;
-    constexpr int NP = PXL / 2;
-    DualRow<NP> inb[2], o1[2];
-    v2f sol1[NP], sol2[NP];
-    v2f xk[2][NP];        // x rows read for stage k1 (row a1 = a2 + 2), reused by stage k2 two ticks later: one ring read per tick
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      sol1[k] = sol2[k] = pk_set(0.f);
-      xk[0][k] = xk[1][k] = pk_set(0.f);
-#pragma unroll
-      for (int pp = 0; pp < 2; ++pp) {
-        inb[pp].rr[k] = inb[pp].ss[k] = inb[pp].p[k] = inb[pp].q[k] = pk_set(0.f);
-        o1[pp].rr[k] = o1[pp].ss[k] = o1[pp].p[k] = o1[pp].q[k] = pk_set(0.f);
-      }
-    }
-    auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
-      constexpr int P = decltype(uu)::value & 1;
-      const int a2 = t - E - 2 * k2, a1 = t - E - 2 * k1;
-      {   // stage k2 on row a2: inputs are this wave's stage k1, one tick (row a2) and two ticks (row a2-1) old
-        const float cdown = ((unsigned)(a2 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
-        DualRow<NP> out;
-        pipe_stage<NP>(xk[P], o1[P ^ 1].rr, o1[P ^ 1].ss, o1[P], sol2, gam, cdown, cstep, cr_last, beta2, out);
-        if (!CHAIN || wave < NT) {
-          float* hb = hout + P * 4 * BW;
-          pairs_store<NP>(hb, lane, out.rr);
-          pairs_store<NP>(hb + BW, lane, out.ss);
-          pairs_store<NP>(hb + 2 * BW, lane, out.p);
-          pairs_store<NP>(hb + 3 * BW, lane, out.q);
-        } else {
-          float* hb = hout + P * 2 * BW;                   // last boundary of a chained launch: rr, ss for the final primal step ...
-          pairs_store<NP>(hb, lane, out.rr);
-          pairs_store<NP>(hb + BW, lane, out.ss);
-          const int b2 = a2 - 1;                           // ... and the whole dual state of row b2 for the next link
-          if (sout && b2 >= 0 && b2 < H) {
-#pragma unroll
-            for (int g = 0; g < NP / 2; ++g) {
-              if (c0 + 4 * g < W) {
-                float* d = sout + (size_t)b2 * W + c0 + 4 * g;
-                *reinterpret_cast<float4*>(d) = make_float4(out.rr[2 * g].x, out.rr[2 * g].y, out.rr[2 * g + 1].x, out.rr[2 * g + 1].y);
-                *reinterpret_cast<float4*>(d + img) = make_float4(out.ss[2 * g].x, out.ss[2 * g].y, out.ss[2 * g + 1].x, out.ss[2 * g + 1].y);
-                *reinterpret_cast<float4*>(d + 2 * img) = make_float4(out.p[2 * g].x, out.p[2 * g].y, out.p[2 * g + 1].x, out.p[2 * g + 1].y);
-                *reinterpret_cast<float4*>(d + 3 * img) = make_float4(out.q[2 * g].x, out.q[2 * g].y, out.q[2 * g + 1].x, out.q[2 * g + 1].y);
-              }
-            }
-          }
-        }
-      }
-      {   // stage k1 on row a1: inputs from the previous wave's hand-off (row a1) and the one read a tick earlier (row a1-1)
-        if constexpr (!FIRST) {
-          if (k1 > 1 || from_state) {
-            const float* hb = hin + (P ^ 1) * 4 * BW;
-            pairs_load<NP>(inb[P].rr, hb, lane);
-            pairs_load<NP>(inb[P].ss, hb + BW, lane);
-            pairs_load<NP>(inb[P].p, hb + 2 * BW, lane);
-            pairs_load<NP>(inb[P].q, hb + 3 * BW, lane);
-          }
-        }
-        pairs_load<NP>(xk[P], ring_row(a1), lane);      // read two ticks ago as row a1 = this tick's a2: consumed above
-        const float cdown = ((unsigned)(a1 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
-        if constexpr (FIRST) pipe_stage_first<NP>(xk[P], sol1, cdown, cstep, cr_last, beta1, o1[P]);
-        else pipe_stage<NP>(xk[P], inb[P].rr, inb[P].ss, inb[P ^ 1], sol1, gam, cdown, cstep, cr_last, beta1, o1[P]);
-      }
-      PIPE_TICK_SYNC();
-    };
-    for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
-    };   // t_role
-    if (!CHAIN && wave == 1) t_role(std::true_type{});
-    else t_role(std::false_type{});
-  } else if (wave == NT + 2) {
-    // ---------------- N: Philox normals, one quad row-group ahead of C -------------------------------------
-    // In the tick of row 4q + NI the normals of pixels NI*PXL/4 .. of quad q + 1 are drawn into the other half of the slab
-    // (spread evenly over the ticks: a burst every 4th tick would stall every wave at the barrier).
-    float* const slab = lds + L::o_slab + lane;        // normal (row q of the quad, pixel k) at slab[(q*PXL + k)*64]
-    auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
-      constexpr int U = decltype(uu)::value;
-      constexpr int NI = ((U - D) % 4 + 4) % 4;        // == o & 3  (t = 4m + U)
-      const int o = t - D;
-      if (A.noise_mode == LMC_NOISE_PHILOX && !(CHAIN && A.tv_state_only)) {
-        const int qn = ((o - NI) >> 2) + 1;             // quad row-group being prepared (o - NI is a multiple of 4)
-        if (qn >= 0 && 4 * qn < H) {
-          float* const sl = slab + (qn & 1) * (4 * PXL * 64);
-#pragma unroll
-          for (int kk = 0; kk < PXL / 4; ++kk) {
-            const int k = NI * (PXL / 4) + kk;
-            float n4[4];
-            quad_normals(A.key0, A.key1, A.iteration, A.chain_offset + (uint32_t)chain, (uint32_t)qn * (uint32_t)W + (uint32_t)(c0 + k), n4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sl[(q * PXL + k) * 64] = n4[q];
-          }
-        }
-      }
-      PIPE_TICK_SYNC();
-    };
-    for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
-  } else {
-    // ---------------- C: final primal step, combine, store --------------------------------------------------
-    const float gam = A.tv.gamma;
-    const float* const hin = lds + L::o_hand + (NT - 1) * 8 * BW;      // [2][4][BW], or [2][2][BW] in a chained launch
-    constexpr int HSTR = CHAIN ? 2 * BW : 4 * BW;
-    float* const slab = lds + L::o_slab + lane;        // normal (row q of the quad, pixel k) at slab[(q*PXL + k)*64]
-    double gacc = 0.0;        // sum |grad x_in| (A.g_out)
-    float crr[2][PXL], xprev[PXL];
-#pragma unroll
-    for (int k = 0; k < PXL; ++k) crr[0][k] = crr[1][k] = xprev[k] = 0.f;
-    // rows of the ME-TV term's prox image (A.extra), requested three ticks ahead of their use (slot tick & 3): a load issued at
-    // its point of use would expose an HBM access per tick
-    float exq[4][PXL];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int k = 0; k < PXL; ++k) exq[u][k] = 0.f;
-    if (A.extra) {
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const int r = u - D;
-        gload_raw<PXL>(exq[u], A.extra + (size_t)chain * img + (size_t)min(max(r, 0), H - 1) * W, c0, W);
-      }
-    }
-    auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
-      constexpr int U = decltype(uu)::value, P = U & 1;
-      constexpr int NI = ((U - D) % 4 + 4) % 4;        // == o & 3  (t = 4m + U)
-      const int o = t - D;
-      if (CHAIN && A.tv_state_only) { PIPE_TICK_SYNC(); return; }     // this link only advances the dual state
-      if (A.extra) {
-        const int r3 = o + 3;
-        gload_raw<PXL>(exq[(U + 3) & 3], A.extra + (size_t)chain * img + (size_t)min(max(r3, 0), H - 1) * W, c0, W);
-      }
-      float css[PXL], xo[PXL], gv[PXL], prox[PXL];
-      prow_load<PXL>(crr[P], hin + (P ^ 1) * HSTR, lane);            // rr^K on row o (written last tick)
-      prow_load<PXL>(css, hin + (P ^ 1) * HSTR + BW, lane);
-      prow_load<PXL>(xo, ring_row(o), lane);
-      if (KT > 0 || A.data_kind == LMC_DATA_IDENTITY || A.data_kind == LMC_DATA_MASK) {
-        prow_load<PXL>(gv, lds + L::o_g + (P ^ 1) * BW, lane);
-      } else {                                  // no data term: o_g is never written (stale LDS could hold NaN bit patterns)
-#pragma unroll
-        for (int j = 0; j < PXL; ++j) gv[j] = 0.f;
-      }
-      const float ssl0 = dpp_left0(css[PXL - 1]);
-#pragma unroll
-      for (int j = 0; j < PXL; ++j) {
-        const float ssl = j == 0 ? ssl0 : css[j - 1];
-        prox[j] = fmaf(-gam, (crr[P][j] - crr[P ^ 1][j]) + (css[j] - ssl), xo[j]);
-      }
-      if (A.ncvx_kind == LMC_NCVX_MC_TV) {   // - lambda * A^T(A x / max(|A x|, gamma))  (algs.py:273-277, 291), added to the gradient
-        // rows o-1 (kept in registers: its ring slot is being overwritten by row t this very tick), o, o+1 (ring)
-        float xp[PXL];
-        prow_load<PXL>(xp, ring_row(o + 1), lane);
-        const float xm_r = dpp_right0(xprev[0]), x0_l = dpp_left0(xo[PXL - 1]), x0_r = dpp_right0(xo[0]),
-                    xp_l = dpp_left0(xp[PXL - 1]);
-#pragma unroll
-        for (int j = 0; j < PXL; ++j) {
-          const int col = c0 + j;
-          gv[j] -= A.ncvx_lambda * mc_tv_grad(xprev[j], j == PXL - 1 ? xm_r : xprev[j + 1], j == 0 ? x0_l : xo[j - 1], xo[j],
-                                              j == PXL - 1 ? x0_r : xo[j + 1], j == 0 ? xp_l : xp[j - 1], xp[j], o > 0, o + 1 < H, col > 0,
-                                              col + 1 < W, A.ncvx_gamma);
-        }
-#pragma unroll
-        for (int j = 0; j < PXL; ++j) xprev[j] = xo[j];
-      }
-      if (A.g_out && o >= 0 && o < H) {   // isotropic TV of the input image, row o: forward differences, zero across the last row / column
-        float xq[PXL];
-        prow_load<PXL>(xq, ring_row(o + 1), lane);
-        const float xr_last = dpp_right0(xo[0]);
-        const bool down = o + 1 < H;
-#pragma unroll
-        for (int j = 0; j < PXL; ++j) {
-          const float dx = down ? xq[j] - xo[j] : 0.f;
-          const float dy = (c0 + j + 1 < W) ? (j == PXL - 1 ? xr_last : xo[j + 1]) - xo[j] : 0.f;
-          gacc += (double)__builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
-        }
-      }
-      if (o >= 0 && o < H) {
-        const float* const slr = slab + ((o >> 2) & 1) * (4 * PXL * 64);
-        const size_t go = (size_t)o * W;
-#pragma unroll
-        for (int g = 0; g < PXL / 4; ++g) {
-          if (c0 + 4 * g < W) {
-            float xi[4] = {0.f, 0.f, 0.f, 0.f}, ex[4] = {0.f, 0.f, 0.f, 0.f};
-            if (A.noise_mode == LMC_NOISE_PHILOX) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) xi[q] = slr[(NI * PXL + 4 * g + q) * 64];
-            } else if (A.noise_mode == LMC_NOISE_INJECTED) {
-              const float4 v = *reinterpret_cast<const float4*>(A.noise + (size_t)chain * img + go + c0 + 4 * g);
-              xi[0] = v.x; xi[1] = v.y; xi[2] = v.z; xi[3] = v.w;
-            }
-            if (A.extra) { ex[0] = exq[U][4 * g]; ex[1] = exq[U][4 * g + 1]; ex[2] = exq[U][4 * g + 2]; ex[3] = exq[U][4 * g + 3]; }
-            float ov[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float x = xo[4 * g + q];
-              float gr = gv[4 * g + q];
-              if (A.extra) gr = fmaf(A.extra_coef, x - ex[q], gr);
-              ov[q] = fmaf(A.a, x, fmaf(-A.t, gr, fmaf(A.b, prox[4 * g + q], A.s * xi[q])));
-            }
-            *reinterpret_cast<float4*>(xout + go + c0 + 4 * g) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-          }
-        }
-      }
-      PIPE_TICK_SYNC();
-    };
-    for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
-    if (A.g_out) {
-      const double tot = wave_sum(gacc);
-      if (lane == 0) unsafeAtomicAdd(&A.g_out[chain], (double)A.g_scale * tot);
-    }
-  }
-}
-
 int centred_blur_taps(const StepArgs& a, float* uc, float* vc);   // lmc_step_rows.hip
 
-template <int K, int PXL, int KT, bool CHAIN = false>
-static constexpr size_t pipe_lds_bytes() { return sizeof(float) * (size_t)PipeLds<K, PXL, CHAIN>::total; }
-
-// Number of links a configuration needs (0: not covered): 10 dual iterations per launch; more (20, 30, ... 60) as a chain of
-// launches that hand the dual state (rr, ss, p, q) over in HBM -- exact, the same mechanism as the tile kernel's chunks.
-int pipe_links(const StepArgs& a) {
-  if (a.prior_kind != LMC_PRIOR_TV_ISO || a.tv.niter > kMaxTvIters) return 0;
-  // one launch: 2, 6, 8, 10 (measured at 512x512x1024: 0.99 / 1.60 / 1.79 / 1.85 ms vs 1.25 / 1.78 / 2.10 / 2.36 split; 4: 1.53 vs 1.42, left to split)
-  const bool single = a.tv.niter == 2 || a.tv.niter == 6 || a.tv.niter == 8 || a.tv.niter == 10;
-  if (!single && (a.tv.niter < 20 || a.tv.niter % 10)) return 0;                                                     // 20, 30, ... 60: chained
-  if (a.prox_ext || a.tv_in || a.tv_out || a.tv_state_only) return 0;
+// image geometry and data term the kernel covers (whatever the number of dual iterations)
+static bool pipe_geometry_ok(const StepArgs& a) {
+  if (a.prior_kind != LMC_PRIOR_TV_ISO || a.prox_ext) return false;
   // 8 (4) pixels per lane above (up to) 256 columns; narrower than 129 columns half the lanes idle and the split kernel wins
-  if (a.W > 512 || a.W <= 128 || (a.W & (a.W > 256 ? 7 : 3)) || a.H < 1) return 0;
+  if (a.W > 512 || a.W <= 128 || (a.W & (a.W > 256 ? 7 : 3)) || a.H < 1) return false;
   if (a.data_kind == LMC_DATA_BLUR) {
     float uc[kMaxBlur], vc[kMaxBlur];
-    if (centred_blur_taps(a, uc, vc) == 0) return 0;
+    if (centred_blur_taps(a, uc, vc) == 0) return false;
   } else if (a.data_kind != LMC_DATA_NONE && a.data_kind != LMC_DATA_IDENTITY && a.data_kind != LMC_DATA_MASK) {
-    return 0;
+    return false;
   }
   // without a blur (no data term, or a pointwise one formed in the load wave): no extra gradient terms, no energy by-products
-  if (a.data_kind != LMC_DATA_BLUR && (a.ncvx_kind != LMC_NCVX_NONE || a.f_out)) return 0;
-  return single ? 1 : a.tv.niter / 10;
+  if (a.data_kind != LMC_DATA_BLUR && (a.ncvx_kind != LMC_NCVX_NONE || a.f_out)) return false;
+  return true;
+}
+
+// Number of launches a configuration needs (0: not covered).  One launch: 2, 6, 8, 9 or 10 dual iterations (9 = the "lagged" reading of
+// niter = 10, lmc_problem.tv_lagged_output).  More (19, 20, 29, 30, ... 60): a chain of launches of 10 (the last one 9 or 10) that hand the
+// dual state (rr, ss, p, q) over in HBM -- exact, the same mechanism as the tile kernel's chunks.
+// (measured at 512x512x1024: K = 2 / 6 / 8 / 10: 0.99 / 1.60 / 1.79 / 1.85 ms vs 1.25 / 1.78 / 2.10 / 2.36 split; 4: 1.53 vs 1.42, left to split)
+int pipe_links(const StepArgs& a) {
+  if (a.prior_kind != LMC_PRIOR_TV_ISO || a.tv.niter > kMaxTvIters) return 0;
+  const int n = a.tv.niter;
+  const bool single = n == 2 || n == 6 || n == 8 || n == 9 || n == 10;
+  if (!single && (n < 19 || (n % 10 != 0 && n % 10 != 9))) return 0;
+  if (a.tv_in || a.tv_out || a.tv_state_only || a.tv_warm) return 0;
+  if (!pipe_geometry_ok(a)) return 0;
+  return single ? 1 : (n + 9) / 10;
 }
 
 bool pipe_supported(const StepArgs& a) { return pipe_links(a) == 1; }
 
-template <int PXL, int KT, bool CHAIN, int K = 10>
-static hipError_t pipe_launch_one(const StepArgs& a, hipStream_t st) {
-  auto kern = myula_step_pipe_kernel<K, PXL, KT, CHAIN>;
-  constexpr size_t lb = pipe_lds_bytes<K, PXL, KT, CHAIN>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(a.C), dim3(64 * (K / 2 + 3)), lb, st, a);
-  return hipGetLastError();
+// warm-started prox: the projected dual (p, q) of the previous MYULA iteration comes in through a.tv_in and the new one leaves through
+// a.tv_out ([C][2][H][W] each, never NULL), a.tv.niter in {1, 2, 3, 9, 10} dual iterations per MYULA iteration
+bool pipe_warm_supported(const StepArgs& a) {
+  const int n = a.tv.niter;
+  if (!(n == 1 || n == 2 || n == 3 || n == 9 || n == 10)) return false;
+  return pipe_geometry_ok(a);
 }
 
-template <bool CHAIN>
-static hipError_t pipe_dispatch(const StepArgs& a, int KT, hipStream_t st) {
-  if (a.W > 256) {
-    if (KT == 5) return pipe_launch_one<8, 5, CHAIN>(a, st);
-    if (KT == 7) return pipe_launch_one<8, 7, CHAIN>(a, st);
-    return pipe_launch_one<8, 0, CHAIN>(a, st);
-  }
-  if (KT == 5) return pipe_launch_one<4, 5, CHAIN>(a, st);
-  if (KT == 7) return pipe_launch_one<4, 7, CHAIN>(a, st);
-  return pipe_launch_one<4, 0, CHAIN>(a, st);
-}
-
-// fewer dual iterations (2, 4, 6, 8): the same kernel with fewer TV waves
-template <int K>
-static hipError_t pipe_dispatch_k(const StepArgs& a, int KT, hipStream_t st) {
-  if (a.W > 256) {
-    if (KT == 5) return pipe_launch_one<8, 5, false, K>(a, st);
-    if (KT == 7) return pipe_launch_one<8, 7, false, K>(a, st);
-    return pipe_launch_one<8, 0, false, K>(a, st);
-  }
-  if (KT == 5) return pipe_launch_one<4, 5, false, K>(a, st);
-  if (KT == 7) return pipe_launch_one<4, 7, false, K>(a, st);
-  return pipe_launch_one<4, 0, false, K>(a, st);
-}
-
-// state0 / state1: [C][4][H][W] ping-pong buffers for the dual state between links (needed when a.tv.niter > 10)
-hipError_t launch_step_pipe(StepArgs a, hipStream_t st, float* state0, float* state1) {
-  const int links = pipe_links(a);
-  if (links == 0 || (links > 1 && (!state0 || !state1))) return hipErrorInvalidConfiguration;
+static int pipe_taps(StepArgs& a) {
   int KT = 0;
   if (a.data_kind == LMC_DATA_BLUR) {
     float uc[kMaxBlur] = {0}, vc[kMaxBlur] = {0};
     KT = centred_blur_taps(a, uc, vc);
     for (int i = 0; i < kMaxBlur; ++i) { a.blur.h[i] = i < KT ? uc[i] : 0.f; a.blur.h[kMaxBlur + i] = i < KT ? vc[i] : 0.f; }
   }
+  return KT;
+}
+
+hipError_t launch_step_pipe_warm(StepArgs a, hipStream_t st) {
+  if (!pipe_warm_supported(a) || !a.tv_in || !a.tv_out || a.tv_in == a.tv_out) return hipErrorInvalidConfiguration;
+  a.tv_warm = 1;
+  a.tv_state_only = 0;
+  const int KT = pipe_taps(a);
+  return pipe_dispatch_chain(a, a.tv.niter, KT, st);
+}
+
+// state0 / state1: [C][4][H][W] ping-pong buffers for the dual state between links (needed when a.tv.niter > 10)
+hipError_t launch_step_pipe(StepArgs a, hipStream_t st, float* state0, float* state1) {
+  const int links = pipe_links(a);
+  if (links == 0 || (links > 1 && (!state0 || !state1))) return hipErrorInvalidConfiguration;
+  const int KT = pipe_taps(a);
   if (links == 1) {
     switch (a.tv.niter) {
-      case 2: return pipe_dispatch_k<2>(a, KT, st);
-      case 6: return pipe_dispatch_k<6>(a, KT, st);
-      case 8: return pipe_dispatch_k<8>(a, KT, st);
-      default: return pipe_dispatch<false>(a, KT, st);
+      case 2: return pipe_dispatch_k<2, false>(a, KT, st);
+      case 6: return pipe_dispatch_k<6, false>(a, KT, st);
+      case 8: return pipe_dispatch_k<8, false>(a, KT, st);
+      case 9: return pipe_dispatch_k<9, false>(a, KT, st);
+      default: return pipe_dispatch_k<10, false>(a, KT, st);
     }
   }
   float* st_buf[2] = {state0, state1};
   for (int j = 0; j < links; ++j) {
     StepArgs b = a;
-    b.tv.niter = 10;
-    for (int i = 0; i < 10; ++i) b.tv.betas[i] = a.tv.betas[10 * j + i];
+    const int kl = (j == links - 1) ? a.tv.niter - 10 * j : 10;      // 10, or 9 in the last link
+    b.tv.niter = kl;
+    for (int i = 0; i < kl; ++i) b.tv.betas[i] = a.tv.betas[10 * j + i];
     b.tv_in = j > 0 ? st_buf[(j - 1) & 1] : nullptr;
     b.tv_out = j < links - 1 ? st_buf[j & 1] : nullptr;
     b.tv_state_only = j < links - 1;
     // the data term, the noise and the energies belong to the last link only; the earlier ones skip the blur pipeline
-    hipError_t e = pipe_dispatch<true>(b, b.tv_state_only ? 0 : KT, st);
+    hipError_t e = pipe_dispatch_chain(b, kl, b.tv_state_only ? 0 : KT, st);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kPtThreads) void myula_step_point_kernel(const Step
   }
 }
 
-bool separate_blur_taps(const BlurTaps& T, float* u, float* v);  // lmc_step_stream.hip
+bool separate_blur_taps(const BlurTaps& T, float* u, float* v);  // lmc_step_rows.hip
 
 bool point_supported(const StepArgs& a) {
   if (a.prior_kind == LMC_PRIOR_TV_ISO) return false;

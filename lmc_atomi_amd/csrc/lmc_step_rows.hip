@@ -266,7 +266,22 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   }
 }
 
-bool separate_blur_taps(const BlurTaps& T, float* u, float* v);  // lmc_step_stream.hip
+// Rank-1 factorisation h = u v^T of the blur taps (u: kh, v: kw).  Returns false if h is not separable.
+bool separate_blur_taps(const BlurTaps& T, float* u, float* v) {
+  int pa = 0, pb = 0;
+  float best = 0.f;
+  for (int a = 0; a < T.kh; ++a)
+    for (int b = 0; b < T.kw; ++b)
+      if (fabsf(T.h[a * T.kw + b]) > best) { best = fabsf(T.h[a * T.kw + b]); pa = a; pb = b; }
+  if (best == 0.f) return false;
+  const float piv = T.h[pa * T.kw + pb];
+  for (int a = 0; a < T.kh; ++a) u[a] = T.h[a * T.kw + pb] / piv;
+  for (int b = 0; b < T.kw; ++b) v[b] = T.h[pa * T.kw + b];
+  for (int a = 0; a < T.kh; ++a)
+    for (int b = 0; b < T.kw; ++b)
+      if (fabsf(u[a] * v[b] - T.h[a * T.kw + b]) > 1e-6f * best) return false;
+  return true;
+}
 
 // Centred taps: the window of a kh-tap kernel with offset oy is rows r+oy-kh+1 .. r+oy; with KT = 2*HW+1 taps centred
 // on r that is u'[a + HW - oy] = u[a], which needs 0 <= HW - oy and kh + HW - oy <= KT.

@@ -528,7 +528,7 @@ static hipError_t launch_split_kt(const StepArgs& a, int KT, hipStream_t st) {
   return launch_split_k<K, 7>(a, st);
 }
 
-bool separate_blur_taps(const BlurTaps& T, float* u, float* v);  // lmc_step_stream.hip
+bool separate_blur_taps(const BlurTaps& T, float* u, float* v);  // lmc_step_rows.hip
 
 static int split_k(const StepArgs& a) { return a.prior_kind == LMC_PRIOR_TV_ISO ? a.tv.niter : 0; }
 

@@ -330,9 +330,9 @@ hipError_t launch_step_tile_chunked(const StepArgs& a, float* state0, float* sta
 __global__ __launch_bounds__(256) void sqdiff_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t img,
                                                      double* __restrict__ out) {
   __shared__ double scratch[4];
-  const size_t c = blockIdx.y;
+  const size_t c = blockIdx.x;      // images on gridDim.x (no 65535 limit)
   double acc = 0.0;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.x * blockDim.x) {
+  for (size_t k = (size_t)blockIdx.y * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.y * blockDim.x) {
     const double d = (double)a[c * img + k] - (double)b[c * img + k];
     acc += d * d;
   }
@@ -355,7 +355,7 @@ hipError_t launch_sqdiff(const float* a, const float* b, int64_t n_img, size_t i
   if (e != hipSuccess) return e;
   int gx = (int)((img + 255) / 256);
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(sqdiff_kernel, dim3(gx, (unsigned)n_img), dim3(256), 0, st, a, b, img, out);
+  hipLaunchKernelGGL(sqdiff_kernel, dim3((unsigned)n_img, gx), dim3(256), 0, st, a, b, img, out);
   return hipGetLastError();
 }
 

@@ -112,30 +112,14 @@ hipError_t ulpda_ncvx_rhs(const float* v, const float* htb, float* rhs, int64_t 
   return hipGetLastError();
 }
 
-// q = p + ts * (second operand already holds H^T H p): q = p + ts*hthp ; accumulate dot(p, q) per chain
-__global__ __launch_bounds__(256) void cg_q_kernel(const float* __restrict__ p, float* __restrict__ q /* in: HtHp, out: q */,
-                                                   size_t img, float ts, double* __restrict__ pq) {
-  __shared__ double scratch[4];
-  const size_t c = blockIdx.y;
-  double acc = 0.0;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.x * blockDim.x) {
-    const float pv = p[c * img + k];
-    const float qv = fmaf(ts, q[c * img + k], pv);
-    q[c * img + k] = qv;
-    acc += (double)pv * (double)qv;
-  }
-  const double t = block_sum(acc, scratch);
-  if (threadIdx.x == 0) unsafeAtomicAdd(&pq[c], t);
-}
-
 // r = rhs - q ; p = r ; rs = dot(r, r)       (CG start, q = A u0)
 __global__ __launch_bounds__(256) void cg_init_kernel(const float* __restrict__ rhs, const float* __restrict__ q,
                                                       float* __restrict__ r, float* __restrict__ p, size_t img,
                                                       double* __restrict__ rs, double* __restrict__ b2) {
   __shared__ double scratch[4];
-  const size_t c = blockIdx.y;
+  const size_t c = blockIdx.x;
   double acc = 0.0, accb = 0.0;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.x * blockDim.x) {
+  for (size_t k = (size_t)blockIdx.y * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.y * blockDim.x) {
     const float bv = rhs[c * img + k];
     const float rv = bv - q[c * img + k];
     r[c * img + k] = rv;
@@ -190,11 +174,11 @@ __global__ __launch_bounds__(256) void cg_update_kernel(float* __restrict__ u, f
                                                         const int* __restrict__ done) {
   __shared__ double scratch[4];
   if (done && *done) return;
-  const size_t c = blockIdx.y;
+  const size_t c = blockIdx.x;
   const double den = pq[c];
   const float alpha = (rs[c] > 0.0 && den != 0.0) ? (float)(rs[c] / den) : 0.f;   // rs == 0: converged, freeze
   double acc = 0.0;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.x * blockDim.x) {
+  for (size_t k = (size_t)blockIdx.y * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.y * blockDim.x) {
     u[c * img + k] = fmaf(alpha, p[c * img + k], u[c * img + k]);
     const float rv = fmaf(-alpha, q[c * img + k], r[c * img + k]);
     r[c * img + k] = rv;
@@ -209,9 +193,9 @@ __global__ __launch_bounds__(256) void cg_dir_kernel(float* __restrict__ p, cons
                                                      double* __restrict__ rs, const double* __restrict__ rs_new,
                                                      const int* __restrict__ done) {
   if (done && *done) return;
-  const size_t c = blockIdx.y;
+  const size_t c = blockIdx.x;
   const float beta = rs[c] > 0.0 ? (float)(rs_new[c] / rs[c]) : 0.f;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.x * blockDim.x)
+  for (size_t k = (size_t)blockIdx.y * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.y * blockDim.x)
     p[c * img + k] = fmaf(beta, p[c * img + k], r[c * img + k]);
 }
 
@@ -246,18 +230,19 @@ __global__ __launch_bounds__(256) void cg_dot_kernel(const float* __restrict__ p
                                                      double* __restrict__ pq, const int* __restrict__ done) {
   __shared__ double scratch[4];
   if (done && *done) return;
-  const size_t c = blockIdx.y;
+  const size_t c = blockIdx.x;
   double acc = 0.0;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.x * blockDim.x)
+  for (size_t k = (size_t)blockIdx.y * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.y * blockDim.x)
     acc += (double)p[c * img + k] * (double)q[c * img + k];
   const double t = block_sum(acc, scratch);
   if (threadIdx.x == 0) unsafeAtomicAdd(&pq[c], t);
 }
 
+// chains on gridDim.x (no 65535 limit), pixel blocks of one image on gridDim.y
 static inline dim3 cg_grid(size_t img, int64_t C) {
-  int gx = (int)((img + 255) / 256);
-  if (gx > 128) gx = 128;
-  return dim3(gx, (unsigned)C);
+  int gy = (int)((img + 255) / 256);
+  if (gy > 128) gy = 128;
+  return dim3((unsigned)C, gy);
 }
 
 hipError_t cg_dot(const float* p, const float* q, int64_t C, size_t img, double* pq, const int* done, hipStream_t st) {
@@ -459,37 +444,6 @@ hipError_t ulpda_finish(float* x, float* xhat, const float* u, const float* xi, 
     return hipGetLastError();
   }
   hipLaunchKernelGGL(ulpda_finish_kernel, dim3(grid1d(total, 256)), dim3(256), 0, st, x, xhat, u, xi, total, s, theta);
-  return hipGetLastError();
-}
-
-// Solve (I + ts H^T H) u = rhs for every chain with `niter` CG iterations from the current content of u.
-// Scratch: r, p, q, tmp [C][H][W]; scal: 3*C doubles (rs, pq, rs_new).
-hipError_t ulpda_cg_solve(float* u, const float* rhs, float* r, float* p, float* q, float* tmp, double* scal, int64_t C, int H,
-                          int W, const BlurTaps& T, float ts, int niter, hipStream_t st) {
-  const size_t img = (size_t)H * W;
-  double* rs = scal;
-  double* pq = scal + C;
-  double* rs_new = scal + 2 * C;
-  int gx = (int)((img + 255) / 256);
-  if (gx > 128) gx = 128;
-  const dim3 grid(gx, (unsigned)C), block(256);
-  hipError_t e;
-  if ((e = hipMemsetAsync(scal, 0, sizeof(double) * 3 * C, st)) != hipSuccess) return e;
-  // q = A u
-  if ((e = launch_blur(u, tmp, C, H, W, T, 0, st)) != hipSuccess) return e;
-  if ((e = launch_blur(tmp, q, C, H, W, T, 1, st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(cg_q_kernel, grid, block, 0, st, u, q, img, ts, pq);
-  hipLaunchKernelGGL(cg_init_kernel, grid, block, 0, st, rhs, q, r, p, img, rs, (double*)nullptr);
-  for (int it = 0; it < niter; ++it) {
-    if ((e = hipMemsetAsync(pq, 0, sizeof(double) * C, st)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(rs_new, 0, sizeof(double) * C, st)) != hipSuccess) return e;
-    if ((e = launch_blur(p, tmp, C, H, W, T, 0, st)) != hipSuccess) return e;
-    if ((e = launch_blur(tmp, q, C, H, W, T, 1, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(cg_q_kernel, grid, block, 0, st, p, q, img, ts, pq);
-    hipLaunchKernelGGL(cg_update_kernel, grid, block, 0, st, u, r, p, q, img, rs, pq, rs_new, (const int*)nullptr);
-    hipLaunchKernelGGL(cg_dir_kernel, grid, block, 0, st, p, r, img, rs, rs_new, (const int*)nullptr);
-    if ((e = hipMemcpyAsync(rs, rs_new, sizeof(double) * C, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
-  }
   return hipGetLastError();
 }
 

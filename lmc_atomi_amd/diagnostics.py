@@ -42,7 +42,7 @@ def chain_probes(x, grid=(8, 8), dims=None, out=None):
         out = torch.empty((n_img, ph * pw), dtype=torch.float32, device=xt.device)
     elif out.numel() != n_img * ph * pw or out.dtype != torch.float32 or not out.is_contiguous():
         raise ValueError("out must be a contiguous float32 tensor of n_img*ph*pw values")
-    _capi.check(_dev.lib().lmc_chain_probes(_dev.ptr(xt), _dev.ptr(out), n_img, H, W, ph, pw, _dev.stream_ptr()))
+    _dev.run(xt, "lmc_chain_probes", _dev.ptr(xt), _dev.ptr(out), n_img, H, W, ph, pw)
     return out
 
 

@@ -92,9 +92,9 @@ class Convolve2D(LinearOperator):
         t, n_img, _ = self._batch(x, self.shape[1])
         out = torch.empty_like(t)
         kh, kw = self.h.shape
-        _capi.check(_dev.lib().lmc_blur(_dev.ptr(t), _dev.ptr(out), n_img, self.dims[0], self.dims[1],
+        _dev.run(t, "lmc_blur", _dev.ptr(t), _dev.ptr(out), n_img, self.dims[0], self.dims[1],
                                         _dev.fptr(self.h), kh, kw, self.offset[0], self.offset[1],
-                                        1 if adjoint else 0, _dev.stream_ptr()))
+                                        1 if adjoint else 0)
         return _dev.like_input(out.reshape(tuple(np.shape(x))), x)
 
     def matvec(self, x):
@@ -120,8 +120,7 @@ class Gradient(LinearOperator):
         import torch
         t, n_img, lead = self._batch(x, self.shape[1])
         out = torch.empty((n_img, 2 * self.shape[1]), dtype=torch.float32, device=t.device)
-        _capi.check(_dev.lib().lmc_gradient(_dev.ptr(t), _dev.ptr(out), n_img, self.dims[0], self.dims[1],
-                                            _dev.stream_ptr()))
+        _dev.run(t, "lmc_gradient", _dev.ptr(t), _dev.ptr(out), n_img, self.dims[0], self.dims[1])
         return _dev.like_input(out.reshape(lead + (2 * self.shape[1],)), x)
 
     def rmatvec(self, y):
@@ -133,8 +132,7 @@ class Gradient(LinearOperator):
         t = t.reshape(-1, self.shape[0])
         n_img = t.shape[0]
         out = torch.empty((n_img, self.shape[1]), dtype=torch.float32, device=t.device)
-        _capi.check(_dev.lib().lmc_gradient_adjoint(_dev.ptr(t), _dev.ptr(out), n_img, self.dims[0], self.dims[1],
-                                                    _dev.stream_ptr()))
+        _dev.run(t, "lmc_gradient_adjoint", _dev.ptr(t), _dev.ptr(out), n_img, self.dims[0], self.dims[1])
         return _dev.like_input(out.reshape(lead + (self.shape[1],)), y)
 
 

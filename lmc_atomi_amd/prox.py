@@ -18,8 +18,8 @@ def _run(kind, x, *params):
     xt = _dev.to_dev(x)
     out = torch.empty_like(xt)
     par = np.asarray(params, dtype=np.float32)
-    _capi.check(_dev.lib().lmc_prox_elementwise(kind, _dev.ptr(xt), _dev.ptr(out), xt.numel(), _dev.fptr(par),
-                                                par.size, _dev.stream_ptr()))
+    _dev.run(xt, "lmc_prox_elementwise", kind, _dev.ptr(xt), _dev.ptr(out), xt.numel(), _dev.fptr(par),
+                                                par.size)
     return _dev.like_input(out, x)
 
 

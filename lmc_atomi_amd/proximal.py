@@ -10,6 +10,7 @@ are added as functors compiled into the library.
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 
 import numpy as np
 import torch
@@ -55,8 +56,10 @@ class _Problem:
     """Assembles an ``lmc_problem`` from a data-term descriptor and a prior descriptor and keeps
     every buffer it points to alive."""
 
-    def __init__(self, dims, data=None, prior=None, dev=None):
+    def __init__(self, dims, data=None, prior=None, dev=None, options=None):
         self.dims = (int(dims[0]), int(dims[1]))
+        self.device = _dev.device(dev)
+        dev = self.device
         p = _capi.lmc_problem()
         p.struct_size = C.sizeof(_capi.lmc_problem)
         p.H, p.W = self.dims
@@ -93,27 +96,36 @@ class _Problem:
         p.ncvx_lambda = float(data.get("ncvx_lambda", 0.0))
         p.ncvx_gamma = float(data.get("ncvx_gamma", 1.0))
         p.ncvx_niter = int(data.get("ncvx_niter", 0))
+        # ABI 2: which truncated iterate the TV prox returns, warm-started dual, per-problem kernel variant / solver tolerance
+        opt = dict(options or {})
+        p.tv_lagged_output = 1 if (prior.get("tv_lagged_output") or data.get("tv_lagged_output") or opt.get("tv_lagged_output")) else 0
+        p.tv_rtol = 0.0                      # the device runs a fixed count (TV / L2_ncvx_tv warn when rtol > 0 is asked for)
+        p.tv_warm = 1 if (prior.get("tv_warm") or opt.get("tv_warm")) else 0
+        v = opt.get("step_variant", 0) or 0
+        p.step_variant = _capi.VARIANTS.index(v) if isinstance(v, str) else int(v)
+        p.implicit_tol = float(opt.get("implicit_tol", data.get("implicit_tol", 0.0)) or 0.0)
         self.c = p
 
     def eval(self, x, a, t, b, pt):
         """out = a*x - t*grad f(x) + b*prox_{pt*g}(x) for image-shaped / flat batches."""
         n = self.dims[0] * self.dims[1]
-        xt = _dev.to_dev(x)
+        xt = _dev.to_dev(x, self.device)
         if xt.numel() % n:
             raise ValueError(f"operand of shape {tuple(xt.shape)} is not a batch of {self.dims} images")
         out = torch.empty_like(xt)
-        _capi.check(_dev.lib().lmc_fused_eval(C.byref(self.c), _dev.ptr(xt), _dev.ptr(out), xt.numel() // n,
-                                              a, t, b, pt, _dev.stream_ptr()))
+        with torch.cuda.device(self.device):       # the problem's buffers (y, mask) live there
+            _dev.run(xt, "lmc_fused_eval", C.byref(self.c), _dev.ptr(xt), _dev.ptr(out), xt.numel() // n,
+                                                  a, t, b, pt)
         return _dev.like_input(out, x)
 
     def energies(self, x):
         n = self.dims[0] * self.dims[1]
-        xt = _dev.to_dev(x)
+        xt = _dev.to_dev(x, self.device)
         n_img = xt.numel() // n
         f = torch.empty(n_img, dtype=torch.float64, device=xt.device)
         g = torch.empty(n_img, dtype=torch.float64, device=xt.device)
-        _capi.check(_dev.lib().lmc_energies(C.byref(self.c), _dev.ptr(xt), n_img, _dev.ptr(f), _dev.ptr(g),
-                                            _dev.stream_ptr()))
+        with torch.cuda.device(self.device):
+            _dev.run(xt, "lmc_energies", C.byref(self.c), _dev.ptr(xt), n_img, _dev.ptr(f), _dev.ptr(g))
         return f, g
 
 
@@ -183,7 +195,7 @@ class L2(ProxOperator):
             return x / (1.0 + tau * self.sigma)
         prob = self._problem()
         n = self.dims[0] * self.dims[1]
-        xt = _dev.to_dev(x)
+        xt = _dev.to_dev(x, prob.device)
         n_img = xt.numel() // n
         lib = _dev.lib()
         if self.warm and self._x0 is not None and self._x0.numel() == xt.numel():
@@ -192,9 +204,10 @@ class L2(ProxOperator):
             out, warm = torch.empty_like(xt), 0
         nbytes = lib.lmc_l2_prox_workspace_bytes(n_img, self.dims[0], self.dims[1])
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xt.device)
-        _capi.check(lib.lmc_l2_prox(C.byref(prob.c), _dev.ptr(xt), _dev.ptr(out), n_img, float(tau), int(self.niter),
-                                    warm, _dev.ptr(ws), _dev.stream_ptr()))
-        torch.cuda.current_stream().synchronize()
+        with torch.cuda.device(prob.device):
+            _capi.check(lib.lmc_l2_prox(C.byref(prob.c), _dev.ptr(xt), _dev.ptr(out), n_img, float(tau), int(self.niter),
+                                        warm, _dev.ptr(ws), _dev.stream_ptr()))
+            torch.cuda.current_stream().synchronize()
         if self.warm:
             self._x0 = out.clone()
         return _dev.like_input(out.reshape(xt.shape), x)
@@ -221,8 +234,8 @@ class L1(ProxOperator):
         xt = _dev.to_dev(x)
         out = torch.empty_like(xt)
         par = np.asarray([self.sigma * float(tau)], dtype=np.float32)
-        _capi.check(_dev.lib().lmc_prox_elementwise(_capi.EPROX_LAPLACE, _dev.ptr(xt), _dev.ptr(out), xt.numel(),
-                                                    _dev.fptr(par), 1, _dev.stream_ptr()))
+        _dev.run(xt, "lmc_prox_elementwise", _capi.EPROX_LAPLACE, _dev.ptr(xt), _dev.ptr(out), xt.numel(),
+                                                    _dev.fptr(par), 1)
         return _dev.like_input(out, x)
 
     def proxdual(self, x, tau):
@@ -230,8 +243,8 @@ class L1(ProxOperator):
         xt = _dev.to_dev(x)
         out = torch.empty_like(xt)
         par = np.asarray([self.sigma], dtype=np.float32)
-        _capi.check(_dev.lib().lmc_prox_elementwise(_capi.EPROX_UNIFORM, _dev.ptr(xt), _dev.ptr(out), xt.numel(),
-                                                    _dev.fptr(par), 1, _dev.stream_ptr()))
+        _dev.run(xt, "lmc_prox_elementwise", _capi.EPROX_UNIFORM, _dev.ptr(xt), _dev.ptr(out), xt.numel(),
+                                                    _dev.fptr(par), 1)
         return _dev.like_input(out, x)
 
 
@@ -256,8 +269,8 @@ class L21(ProxOperator):
         if n2 % 2:
             raise ValueError("stacked field must have even length")
         out = torch.empty_like(xt)
-        _capi.check(_dev.lib().lmc_dual_project(_dev.ptr(xt), _dev.ptr(out), xt.numel() // n2, 1, n2 // 2,
-                                                self.sigma, 1, _dev.stream_ptr()))
+        _dev.run(xt, "lmc_dual_project", _dev.ptr(xt), _dev.ptr(out), xt.numel() // n2, 1, n2 // 2,
+                                                self.sigma, 1)
         return _dev.like_input(out, x)
 
     def prox(self, x, tau):
@@ -265,29 +278,48 @@ class L21(ProxOperator):
         xt = _dev.to_dev(x)
         n2 = xt.shape[-1]
         out = torch.empty_like(xt)
-        _capi.check(_dev.lib().lmc_dual_project(_dev.ptr(xt), _dev.ptr(out), xt.numel() // n2, 1, n2 // 2,
-                                                self.sigma * float(tau), 1, _dev.stream_ptr()))
+        _dev.run(xt, "lmc_dual_project", _dev.ptr(xt), _dev.ptr(out), xt.numel() // n2, 1, n2 // 2,
+                                                self.sigma * float(tau), 1)
         return _dev.like_input(xt - out, x)
 
 
 class TV(ProxOperator):
     """``sigma * TV_iso(x)`` -- drop-in for ``pyproximal.TV(dims=img.shape, sigma=tau, niter=niter_tv)``
     (prox_lmc_deconv.py:122).  ``prox`` runs ``niter`` fast-gradient-projection dual iterations fully
-    on chip (fixed count; the reference's data-dependent ``rtol`` early exit is not taken: a batched
-    launch does identical work for every chain)."""
+    on chip.
 
-    def __init__(self, dims, sigma=1.0, niter=10, rtol=0.0, step=0.125, momentum="unlocbox"):
+    Deviations from upstream, both named in DESIGN section 4:
+
+    * ``rtol``: pyproximal's per-image early exit on the relative change of the primal objective (its default 1e-4, which the
+      reference's call does not override) is NOT taken -- a batched launch does identical work for every chain.  The default
+      here is therefore 0; a positive value is stored, ignored by the device and answered with a ``RuntimeWarning``.
+      Parity with the CPU checker under ``tests/`` holds at ``rtol = 0``.
+    * ``lagged_output``: whether upstream's truncated iterate after ``niter`` loop passes reflects ``niter`` or ``niter - 1`` dual
+      updates depends on the loop bound of the un-pinned upstream version; ``False`` (default) = ``niter`` updates,
+      ``True`` = ``niter - 1`` (one pipeline stage fewer).
+    * ``warm`` (build extension, MYULA samplers only): carry the projected dual from one MYULA iteration to the next, ``niter``
+      in {1, 2, 3, 9, 10} updates per MYULA iteration ("K in {1,3} warm-dual")."""
+
+    def __init__(self, dims, sigma=1.0, niter=10, rtol=0.0, step=0.125, momentum="unlocbox", lagged_output=False, warm=False):
         super().__init__(None, False)
         self.dims = (int(dims[0]), int(dims[1]))
         self.sigma = float(sigma)
         self.niter = int(niter)
+        self.rtol = float(rtol)
+        if self.rtol > 0.0:
+            warnings.warn(f"TV(rtol={self.rtol:g}): the per-image early exit of pyproximal.TV is not taken on the GPU -- every chain "
+                          f"runs {'niter - 1' if lagged_output else 'niter'} = {self.niter - (1 if lagged_output else 0)} dual "
+                          "iterations (parity with the CPU checker holds at rtol = 0)", RuntimeWarning, stacklevel=2)
         self.step = float(step)
         self.momentum = momentum
+        self.lagged_output = bool(lagged_output)
+        self.warm = bool(warm)
         self._prob = None
 
     def prior_descriptor(self):
         return {"prior_kind": _capi.PRIOR_TV_ISO, "prior_sigma": self.sigma, "tv_niter": self.niter,
-                "tv_step": self.step, "tv_betas": fgp_betas(self.niter, self.momentum)}
+                "tv_step": self.step, "tv_betas": fgp_betas(self.niter, self.momentum),
+                "tv_lagged_output": self.lagged_output, "tv_warm": self.warm}
 
     def _problem(self):
         if self._prob is None:
@@ -330,8 +362,8 @@ class WaveletL1(ProxOperator):
         xt = _dev.to_dev(x)
         out = torch.empty_like(xt)
         n = self.dims[0] * self.dims[1]
-        _capi.check(_dev.lib().lmc_haar_l1_prox(_dev.ptr(xt), _dev.ptr(out), xt.numel() // n, self.dims[0], self.dims[1],
-                                                self.sigma * float(tau), _dev.stream_ptr()))
+        _dev.run(xt, "lmc_haar_l1_prox", _dev.ptr(xt), _dev.ptr(out), xt.numel() // n, self.dims[0], self.dims[1],
+                                                self.sigma * float(tau))
         return _dev.like_input(out, x)
 
 
@@ -349,7 +381,7 @@ class L2_ncvx_tv(ProxOperator):
     """
 
     def __init__(self, dims, Op=None, Op2=None, b=None, q=None, sigma=1., alpha=1., lamda=1., gamma=.5, qgrad=True,
-                 isotropic=False, niter=10, rtol=1e-4, x0=None, warm=True, densesolver=None, kwargs_solver=None):
+                 isotropic=False, niter=10, rtol=1e-4, x0=None, warm=True, densesolver=None, kwargs_solver=None, lagged_output=False):
         super().__init__(Op, True)
         from .operators import Gradient
         if q is not None:
@@ -367,6 +399,13 @@ class L2_ncvx_tv(ProxOperator):
         self.isotropic = isotropic
         self.niter = niter
         self.warm = warm
+        # the reference hands rtol to its inner TV(dims, 1., niter, rtol) (algs.py:169): that prox is only used by the ME-TV branch
+        self.rtol = float(rtol)
+        if Op2 is None and self.rtol > 0.0:
+            warnings.warn(f"L2_ncvx_tv(rtol={self.rtol:g}): the early exit of the inner pyproximal.TV prox (algs.py:169) is not taken on the "
+                          f"GPU -- every chain runs niter = {int(niter)} dual iterations (pass rtol=0 to silence; parity with the CPU "
+                          "checker holds at rtol = 0)", RuntimeWarning, stacklevel=2)
+        self.lagged_output = bool(lagged_output)
         self._prob = None
 
     def descriptor(self):
@@ -375,7 +414,8 @@ class L2_ncvx_tv(ProxOperator):
         else:
             base = {"data_kind": _capi.DATA_BLUR, "sigma_f": self.sigma, "y": self.b, "h": self.Op.h, "offset": self.Op.offset}
         return {**base, "ncvx_kind": _capi.NCVX_MC_TV if self.Op2 is not None else _capi.NCVX_ME_TV,
-                "ncvx_lambda": self.lamda, "ncvx_gamma": self.gamma, "ncvx_niter": int(self.niter)}
+                "ncvx_lambda": self.lamda, "ncvx_gamma": self.gamma, "ncvx_niter": int(self.niter),
+                "tv_lagged_output": self.lagged_output}
 
     def _problem(self):
         if self._prob is None:
@@ -395,7 +435,7 @@ class L2_ncvx_tv(ProxOperator):
         the reference (which adds the first term into its argument in place, :217) the input is left untouched."""
         prob = self._problem()
         n = self.dims[0] * self.dims[1]
-        xt = _dev.to_dev(x)
+        xt = _dev.to_dev(x, prob.device)
         n_img = xt.numel() // n
         lib = _dev.lib()
         x0 = getattr(self, "_x0", None)
@@ -404,9 +444,10 @@ class L2_ncvx_tv(ProxOperator):
         else:
             out, warm = torch.empty_like(xt), 0
         ws = torch.empty(lib.lmc_l2_prox_workspace_bytes(n_img, self.dims[0], self.dims[1]), dtype=torch.uint8, device=xt.device)
-        _capi.check(lib.lmc_l2_prox(C.byref(prob.c), _dev.ptr(xt), _dev.ptr(out), n_img, float(tau), int(self.niter), warm,
-                                    _dev.ptr(ws), _dev.stream_ptr()))
-        torch.cuda.current_stream().synchronize()
+        with torch.cuda.device(prob.device):
+            _capi.check(lib.lmc_l2_prox(C.byref(prob.c), _dev.ptr(xt), _dev.ptr(out), n_img, float(tau), int(self.niter), warm,
+                                        _dev.ptr(ws), _dev.stream_ptr()))
+            torch.cuda.current_stream().synchronize()
         if self.warm:
             self._x0 = out.clone()
         return _dev.like_input(out.reshape(xt.shape), x)

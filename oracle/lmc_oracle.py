@@ -1037,9 +1037,10 @@ def energies(x, y, h, offset, sigma_f, prior, mask=None):
     return f, g
 
 
-def mymala_batched(x0, y, h, offset, sigma_f, tau, gamma, prior, niter, noise_fn, uniform_fn, mask=None):
+def mymala_batched(x0, y, h, offset, sigma_f, tau, gamma, prior, niter, noise_fn, uniform_fn, mask=None, epsg=1.0):
     """MYMALA for ``C`` image-shaped chains: the accept / reject of ``prox_lmc.py:134-158`` with the MYULA proposal of
-    ``algs.py:569`` and target ``exp(-f - g)``, in log form
+    ``algs.py:569`` and target ``exp(-f - epsg*g)`` (the potential ``f + eps*g`` of algs.py:582 whose gradient the MYULA drift
+    approximates; ``prior['t']`` must hold ``epsg*gamma``), in log form
     ``log alpha = U(x) - U(x') - (||x - m(x')||^2 - ||x' - m(x)||^2) / (4 tau)``; ``noise_fn(k) -> [C,H,W]``,
     ``uniform_fn(k) -> [C]``.  A rejected chain keeps its state.  Returns ``(x, accepted[C], log_alpha[niter, C])``."""
     x = np.array(x0, dtype=np.float64)
@@ -1050,7 +1051,7 @@ def mymala_batched(x0, y, h, offset, sigma_f, tau, gamma, prior, niter, noise_fn
 
     def U(v):
         f, g = energies(v, y, h, offset, sigma_f, prior, mask=mask)
-        return f + g
+        return f + epsg * g
 
     mx, Ux = mean(x), U(x)
     acc = np.zeros(x.shape[0], dtype=np.int64)

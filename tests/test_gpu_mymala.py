@@ -47,22 +47,25 @@ def build(la, kind, shape, rng):
     return img, y, h, off, mask, pf, pg, prior, sigma
 
 
-@pytest.mark.parametrize("kind,tau_scale,shape", [("tv", 0.02, (32, 32)), ("l2", 0.02, (32, 32)), ("haar", 0.02, (32, 32)),
-                                                   ("tv", 1.0, (32, 32)),
-                                                   # wide images: the step kernel returns f(x'), g(x') as by-products
-                                                   ("tv10", 0.02, (24, 160)), ("tv10", 1.0, (20, 264))])
-def test_mymala_matches_oracle_with_injected_noise(la, kind, tau_scale, shape):
+@pytest.mark.parametrize("kind,tau_scale,shape,epsg", [("tv", 0.02, (32, 32), 1.0), ("l2", 0.02, (32, 32), 1.0), ("haar", 0.02, (32, 32), 1.0),
+                                                        ("tv", 1.0, (32, 32), 1.0),
+                                                        # wide images: the step kernel returns f(x'), g(x') as by-products
+                                                        ("tv10", 0.02, (24, 160), 1.0), ("tv10", 1.0, (20, 264), 1.0),
+                                                        # epsg != 1: the Metropolis target is exp(-f - epsg g), the potential of the MYULA drift
+                                                        ("tv", 0.02, (32, 32), 0.5), ("tv10", 0.02, (24, 160), 2.5)])
+def test_mymala_matches_oracle_with_injected_noise(la, kind, tau_scale, shape, epsg):
     rng = np.random.default_rng(17)
     img, y, h, off, mask, pf, pg, prior, sigma = build(la, kind, shape, rng)
     gamma, tau = sigma ** 2, tau_scale * sigma ** 2
+    prior = dict(prior, t=epsg * gamma)
     C, nit, seed, off_c = 6, 6, 1234, 40
     x0 = img[None] + rng.normal(0, 3, (C,) + shape)
     noise = rng.standard_normal((nit, C) + shape)
-    smp = la.MYMALASampler(pf, pg, shape, n_chains=C, tau=tau, gamma=gamma, noise="injected", seed=seed, chain_offset=off_c)
+    smp = la.MYMALASampler(pf, pg, shape, n_chains=C, tau=tau, gamma=gamma, epsg=epsg, noise="injected", seed=seed, chain_offset=off_c)
     smp.set_state(x0)
     us = np.stack([O.philox_uniforms(seed, k, off_c + np.arange(C)) for k in range(nit)])
     xo, acc_o, la_o = O.mymala_batched(x0, y, h, off, 1 / sigma ** 2, tau, gamma, prior, nit, lambda k: noise[k], lambda k: us[k],
-                                       mask=mask)
+                                       mask=mask, epsg=epsg)
     # the device follows the oracle decision unless log u is within the fp32 energy error of log alpha; replay the oracle
     # chain by chain with the device's own decisions to compare states exactly where a borderline decision differs
     x = x0.copy()
@@ -73,7 +76,7 @@ def test_mymala_matches_oracle_with_injected_noise(la, kind, tau_scale, shape):
         las.append(la_d.cpu().numpy())
     las = np.array(las)
     f0, g0 = O.energies(x0, y, h, off, 1 / sigma ** 2, prior, mask=mask)
-    scale = np.abs(f0 + g0).max()
+    scale = np.abs(f0 + epsg * g0).max()
     err = np.abs(las - la_o)
     margin = np.abs(np.log(us) - la_o)
     safe = (margin > 10 * (1e-6 * scale + 1e-3)).all(axis=0)        # chains whose every decision is clear-cut
