@@ -2,7 +2,7 @@
 """bench.py -- LMC chain-iterations/s on MI355X (BASELINE.json metric), with the HBM roofline of the
 fused step kernel and the CPU oracle timed beside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R] [--tv-warm]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -12,6 +12,12 @@ Gaussian noise sigma = 0.75) + isotropic TV prox (niter_tv = 10 dual iterations)
 every rank runs 1024 chains of its own (weak scaling, configs[3]: 8192 chains on 8 GPUs), chains keyed by
 global id, and the only collective is one RCCL all-reduce of the posterior moment images at the end of the
 timed region.  Inputs are synthetic and resident in HBM before the timed region starts.
+
+Protocol: W warm-up steps, then the timed region of EXACTLY K steps (barrier + synchronize on both sides, max over
+ranks) is run R = 3 times back to back and the MEDIAN region is reported (`repeats`, `ms_per_step_all`); the step kernel's launch time
+is the HIP-event average over the launches of that median region, on the launch stream.  `roofline` carries the spec peak, the
+bandwidth a state-shaped copy measures on this device in this process (`peak_measured`), and a `valu` block (vector-ALU busy
+fraction of the same kernel from the committed rocprofv3 counters): at K = 10 the update is bound by VALU issue, not by HBM.
 """
 import argparse
 import json
@@ -104,6 +110,12 @@ def main():
     ap.add_argument("--ncvx-iters", type=int, default=None, help="inner TV-prox iterations of the ME-TV term (default: --tv-iters; the reference uses niter_l2 = 50)")
     ap.add_argument("--noise", default="philox", choices=["philox", "none"], help="noise source (experiments)")
     ap.add_argument("--tau-scale", type=float, default=1.0, help="multiplies the step size tau = 0.2 sigma^2 (MYMALA acceptance experiments)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps; the median is reported (SURVEY 8(d))")
+    ap.add_argument("--tv-warm", action="store_true",
+                    help="warm-dual TV (SURVEY 8(d) C3 variant; build extension): carry the TV dual between MYULA iterations, "
+                         "--tv-iters in {1, 2, 3, 9, 10} per iteration (+16 B/px of HBM traffic, quoted as `actual_bytes_per_launch`)")
+    ap.add_argument("--tv-lagged", action="store_true", help="TV prox after tv_iters - 1 dual updates (lmc_problem.tv_lagged_output)")
+    ap.add_argument("--no-hbm-probe", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chains", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=20)
@@ -158,7 +170,7 @@ def main():
     if args.ncvx != "none":                          # prox_lmc_deconv.py:106-113 (niter of the inner TV prox = --tv-iters)
         pf = la.L2_ncvx_tv(dims=(H, W), Op=pf.Op, Op2=la.Gradient((H, W)) if args.ncvx == "mc" else None, b=pf.b, sigma=1 / sigma ** 2,
                            lamda=tau_reg, gamma=15.0, isotropic=True, niter=args.ncvx_iters or args.tv_iters)
-    pg = {"tv": lambda: la.TV((H, W), sigma=tau_reg, niter=args.tv_iters), "l2": lambda: la.L2(sigma=0.05),
+    pg = {"tv": lambda: la.TV((H, W), sigma=tau_reg, niter=args.tv_iters, warm=args.tv_warm, lagged_output=args.tv_lagged), "l2": lambda: la.L2(sigma=0.05),
           "l1": lambda: la.L1(sigma=tau_reg), "haar": lambda: la.WaveletL1((H, W), sigma=tau_reg)}[args.prior]()
     if args.alg == "ulpda":      # prox_lmc_deconv.py:88-90,455-457: tau0 = 0.95 sigma^2, mu0 = 1, theta = 1, gfirst = False
         pf.niter = args.cg_iters
@@ -177,48 +189,79 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    from lmc_atomi_amd.sharding import allreduce_sampler_moments
+    collective = "none"
+    if use_dist and not args.no_moments:
+        collective = ("lmc_allreduce_moments (C ABI): one ncclAllReduce of {sum x, sum x^2, count} on the process group's RCCL communicator"
+                      if backend == "nccl" else "torch.distributed gloo all-reduce of the packed accumulators (rehearsal)")
     smp.step(args.warmup)
+    reduce_fn = allreduce_sampler_moments
     if not args.no_moments:
         if use_dist:                                 # warm the collective too (communicator set-up, buffers of this size)
-            from lmc_atomi_amd.sharding import allreduce_moments
-            allreduce_moments(*smp.moments())
+            try:
+                allreduce_sampler_moments(smp)
+            except Exception as exc:                 # plumbing, not the compute path: keep the job alive and say so in the JSON line
+                from lmc_atomi_amd.sharding import allreduce_moments
+
+                def reduce_fn(sm):
+                    return allreduce_moments(*sm.moments())
+                reduce_fn(smp)
+                collective = f"torch.distributed all-reduce of the packed accumulators (C-ABI collective unavailable: {exc})"
         smp.reset_moments()
     timed_launches = args.alg == "myula" and os.environ.get("LMC_BENCH_NO_TIMING") != "1"   # experiments: cost of the event records
     if timed_launches:
         smp.enable_timing(True)
-    sync_all()
-    t0 = time.perf_counter()
-    smp.step(args.steps)
-    if use_dist and not args.no_moments:
-        from lmc_atomi_amd.sharding import allreduce_moments
-        s1, s2, cnt = smp.moments()
-        s1, s2, cnt = allreduce_moments(s1, s2, cnt)         # RCCL over xGMI: posterior mean/var accumulators
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-    if timed_launches:
-        kern_ms, launches = smp.last_step_timing()
-    else:                        # ULPDA is a sequence of launches per iteration: quote the whole iteration
-        kern_ms, launches = elapsed * 1e3, args.steps
+    regions = []                                     # (elapsed s of K steps, step-kernel ms summed over its launches, launches)
+    for _ in range(max(1, args.repeats)):
+        if not args.no_moments:
+            smp.reset_moments()
+        sync_all()
+        t0 = time.perf_counter()
+        smp.step(args.steps)
+        if use_dist and not args.no_moments:
+            s1, s2, cnt = reduce_fn(smp)                     # RCCL over xGMI: posterior mean/var accumulators of the whole job
+        sync_all()
+        el = time.perf_counter() - t0
+        if use_dist:
+            te = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        if timed_launches:
+            kms, nl = smp.last_step_timing()
+        else:                    # ULPDA / MYMALA are sequences of launches per iteration: quote the whole iteration
+            kms, nl = el * 1e3, args.steps
+        regions.append((el, kms, nl))
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    elapsed, kern_ms, launches = regions[order[len(order) // 2]]          # the median region
 
     if rank == 0:
         # HBM bytes per launch from the committed rocprofv3 PMC passes (they cannot be collected inside this process);
         # only quoted when the profile is of this kernel on this workload
-        traffic = None
-        try:
-            want = {"H": H, "W": W, "C": C, "prior": args.prior, "data": args.data, "tv_iters": args.tv_iters, "ncvx": args.ncvx}
-            for ent in json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["entries"]:
-                if ent["workload"] == want and ent["kernel"] == smp.kernel_name:
-                    traffic = ent["traffic_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        traffic, valu = None, None
+        want = {"H": H, "W": W, "C": C, "prior": args.prior, "data": args.data, "tv_iters": args.tv_iters, "ncvx": args.ncvx}
+        if args.tv_warm:
+            want["tv_warm"] = True
+        if args.tv_lagged:
+            want["tv_lagged"] = True
+        for prof in ("r02_counters.json", "r01_traffic.json"):       # the newest committed counters of this kernel on this workload
+            try:
+                for ent in json.load(open(os.path.join(ROOT, "profiles", prof)))["entries"]:
+                    if ent["workload"] == want and ent["kernel"] == smp.kernel_name and traffic is None:
+                        traffic = ent["traffic_bytes_per_launch"]
+                        if "valu" in ent:
+                            valu = dict(ent["valu"], source=ent.get("source"))
+            except Exception:
+                pass
+        peak_measured = None
+        if not args.no_hbm_probe:
+            import ctypes
+            g = ctypes.c_float()
+            la._capi.check(la._dev.lib().lmc_hbm_copy_probe(1 << 30, 3, ctypes.byref(g), None))     # 1 GiB read + 1 GiB written, as a state pass
+            peak_measured = float(g.value)
         value = C * world * args.steps / elapsed
         per_launch_ms = kern_ms / launches
         achieved = BYTES_PER_PIXEL_STEP * H * W * C / (per_launch_ms * 1e-3) / 1e9
-        prior_desc = (f"isotropic TV prox K={args.tv_iters} (tau_reg={tau_reg})" if args.prior == "tv"
+        prior_desc = (f"isotropic TV prox K={args.tv_iters}{' warm-dual' if args.tv_warm else ''}{' lagged output' if args.tv_lagged else ''} (tau_reg={tau_reg})" if args.prior == "tv"
                       else f"{args.prior} prior")
         out = {
             "metric": "lmc_chain_iterations_per_s",
@@ -228,6 +271,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "repeats": len(regions), "statistic": "median of the timed regions",
+            "ms_per_step_all": [r[0] / args.steps * 1e3 for r in regions],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -241,6 +286,7 @@ def main():
                 "image": [H, W], "chains_per_gpu": C, "chains_total": C * world, "tv_iters": args.tv_iters,
                 "sampler": "MYULA (algs.py:477-587)" if args.alg == "myula" else "MYMALA (Metropolis-adjusted MYULA, generalises prox_lmc.py:134-158)" if args.alg == "mymala" else f"ULPDA (algs.py:295-474), implicit step by CG: at most {args.cg_iters} iterations, stops at |r| <= 1e-6 |b| for every chain (the reference solver's rule, algs.py:250)", "parallelism": f"chains sharded x{world}",
                 "iterations_per_s": args.steps / elapsed,
+                "collective": collective,
             },
             "roofline": {
                 "bound": "hbm",
@@ -249,12 +295,23 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "peak_measured": peak_measured,
+                "frac_of_measured": (achieved / peak_measured) if peak_measured else None,
+                "peak_measured_how": "lmc_hbm_copy_probe: 1 GiB read + 1 GiB written, float4 per lane, best of 3 after a warm-up, this process",
                 "traffic": traffic,
                 "launch_ms": per_launch_ms,
                 "launches": launches,
                 "algorithmic_bytes_per_launch": BYTES_PER_PIXEL_STEP * H * W * C,
+                # what actually limits the kernel when it is not HBM: vector-ALU busy fraction from the committed counters
+                # (SQ_ACTIVE_INST_VALU quad-cycles x 4 / (SIMDs x kernel cycles), profiles/): ~1 means VALU-issue bound
+                "valu": valu,
+                "limiter": ("valu" if (valu and valu.get("busy_frac", 0) > 0.6 and achieved / HBM_PEAK_GBS < 0.3) else "hbm"),
             },
         }
+        if args.tv_warm:      # the un-fused variant reports its ACTUAL bytes beside the algorithmic 8 B/px
+            out["roofline"]["actual_bytes_per_launch"] = (BYTES_PER_PIXEL_STEP + 16) * H * W * C
+            out["roofline"]["actual_gbs"] = (BYTES_PER_PIXEL_STEP + 16) * H * W * C / (per_launch_ms * 1e-3) / 1e9
+            out["config"]["tv_warm"] = True
         if args.alg == "mymala":
             out["config"]["acceptance_rate_mean"] = float(smp.acceptance_rate().mean())
             out["config"]["tau_scale"] = args.tau_scale

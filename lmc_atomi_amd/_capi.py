@@ -99,6 +99,7 @@ _SIGNATURES = {
     "lmc_version": (C.c_int, []),
     "lmc_last_error": (C.c_char_p, []),
     "lmc_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "lmc_hbm_copy_probe": (C.c_int, [C.c_size_t, C.c_int32, C.POINTER(C.c_float), _P]),
     "lmc_blur": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _F, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "lmc_gradient": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "lmc_gradient_adjoint": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P]),

@@ -555,6 +555,36 @@ int lmc_device_info(int* device, int* n_cu, size_t* lds_bytes, size_t* hbm_bytes
   return LMC_OK;
 }
 
+int lmc_hbm_copy_probe(size_t bytes, int32_t reps, float* gbs_out, void* stream) {
+  if (!gbs_out || reps < 1 || bytes < (1u << 20)) return fail(LMC_E_INVALID, "bad arguments (at least 1 MiB, reps >= 1)");
+  const size_t n = (bytes / 16) * 4;                       // floats, a multiple of 4
+  hipStream_t st = S(stream);
+  float *x = nullptr, *y = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc(&x, n * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&y, n * sizeof(float));
+  if (e == hipSuccess) e = hipMemsetAsync(x, 0, n * sizeof(float), st);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  float best = 0.f;
+  for (int r = 0; r < reps + 1 && e == hipSuccess; ++r) {   // the first pass warms up (page mapping, clocks)
+    e = hipEventRecord(e0, st);
+    if (e == hipSuccess) e = lmc::launch_hbm_copy_probe(x, y, n, st);
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess && r > 0 && ms > 0.f) best = fmaxf(best, (float)(2.0 * (double)n * sizeof(float) / ((double)ms * 1e-3) / 1e9));
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (x) (void)hipFree(x);
+  if (y) (void)hipFree(y);
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LMC_E_NOMEM : LMC_E_HIP, "HBM probe failed: %s", hipGetErrorString(e));
+  *gbs_out = best;
+  return LMC_OK;
+}
+
 int lmc_blur(const float* x_dev, float* out_dev, int64_t n_img, int32_t H, int32_t W, const float* h_host, int32_t kh,
              int32_t kw, int32_t oy, int32_t ox, int32_t adjoint, void* stream) {
   if (!x_dev || !out_dev) return fail(LMC_E_INVALID, "NULL image pointer");

@@ -664,4 +664,20 @@ hipError_t launch_chain_probes(const float* x, float* out, int64_t n_img, int H,
   return hipGetLastError();
 }
 
+// ---- HBM streaming probe: the measured bandwidth the roofline fractions are quoted beside ("confirm on the box with a
+// copy probe and report both").  A state-shaped copy: read one buffer, write another, 16 bytes per lane.
+__global__ __launch_bounds__(256) void hbm_copy_probe_kernel(const float4* __restrict__ x, float4* __restrict__ y, size_t n4, float a) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 v = x[i];
+    v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+    y[i] = v;
+  }
+}
+
+hipError_t launch_hbm_copy_probe(const float* x, float* y, size_t n_floats, hipStream_t st) {
+  hipLaunchKernelGGL(hbm_copy_probe_kernel, dim3(8192), dim3(256), 0, st, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y),
+                     n_floats / 4, 1.0f);
+  return hipGetLastError();
+}
+
 }  // namespace lmc

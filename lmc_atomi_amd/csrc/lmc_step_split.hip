@@ -546,6 +546,7 @@ bool split_supported(const StepArgs& a) {
     case 5: fits = split_fits<5>(NW); break;
     case 6: fits = split_fits<6>(NW); break;
     case 8: fits = split_fits<8>(NW); break;
+    case 9: fits = split_fits<9>(NW); break;      // the lagged reading of niter = 10
     case 12: fits = split_fits<12>(NW); break;
 #endif
     case 10: fits = split_fits<10>(NW); break;
@@ -578,6 +579,7 @@ hipError_t launch_step_split(StepArgs a, hipStream_t st) {
     case 5: return launch_split_kt<5>(a, KT, st);
     case 6: return launch_split_kt<6>(a, KT, st);
     case 8: return launch_split_kt<8>(a, KT, st);
+    case 9: return launch_split_kt<9>(a, KT, st);
     case 12: return launch_split_kt<12>(a, KT, st);
 #endif
     case 10: return launch_split_kt<10>(a, KT, st);

@@ -51,14 +51,17 @@ def rccl_comm(group=None, device=None):
     import ctypes as C
     import torch.distributed as dist
     from . import _capi, _dev
+    import os
     pg = group if group is not None else dist.group.WORLD
     dev = _dev.device(device)
-    try:
-        ptr = int(pg._get_backend(dev)._comm_ptr())
-        if ptr:
-            return ptr
-    except Exception:       # older / different PyTorch: no accessor -- fall through to a communicator of our own
-        pass
+    if os.environ.get("LMC_RCCL_COMM", "torch") != "own":
+        try:
+            with torch.cuda.device(dev):           # the accessor answers for the CURRENT device
+                ptr = int(pg._get_backend(dev)._comm_ptr())
+            if ptr:
+                return ptr
+        except Exception:   # older / different PyTorch: no accessor -- fall through to a communicator of our own
+            pass
     key = id(pg)
     if key in _own_comms:
         return _own_comms[key]

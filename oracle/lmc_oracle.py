@@ -427,7 +427,7 @@ def fgp_betas(niter, momentum="unlocbox", dtype=np.float64):
     return np.asarray(out, dtype=dtype)
 
 
-def tv_prox_fgp(x, gamma, niter, step=0.125, betas=None, rtol=0.0, momentum="unlocbox"):
+def tv_prox_fgp(x, gamma, niter, step=0.125, betas=None, rtol=0.0, momentum="unlocbox", dual0=None, return_dual=False):
     """``prox_{gamma*TV}(x)`` by ``niter`` fast-gradient-projection dual iterations.
 
     Build-specified restatement of ``pyproximal.TV(dims, sigma, niter, rtol).prox``
@@ -444,6 +444,18 @@ def tv_prox_fgp(x, gamma, niter, step=0.125, betas=None, rtol=0.0, momentum="unl
     ``rtol > 0`` adds the reference's per-image early exit on the relative change of the
     primal objective; the device path always runs the fixed ``niter`` (rtol = 0), so a
     batched launch does the same work for every chain (documented deviation).
+
+    NAMED RISK (cannot be settled in this image: pyproximal is neither vendored nor installable).  Upstream forms ``sol`` at the
+    TOP of each loop pass, tests the exit, updates the dual, and returns the ``sol`` of the pass it leaves in.  Whether ``niter``
+    passes leave a ``sol`` that reflects ``niter`` dual updates (loop ``while iter <= niter``, as recalled for pyproximal) or
+    ``niter - 1`` (loop ``while iter < niter``, as in UNLocBoX's prox_tv with ``iter`` starting at 1) depends on the upstream
+    version.  This restatement returns the iterate after ``niter`` updates; the other reading is ``niter - 1`` here, and the
+    device runs either (``lmc_problem.tv_lagged_output``).  Likewise upstream's default ``rtol = 1e-4`` (which the reference's
+    call ``TV(dims, sigma, niter=niter_tv)`` does not override) stops a typical MYULA iterate's prox after about 3 passes
+    (tests/test_oracle_operators.py::test_tv_rtol_exit_statistics); the device and the goldens use ``rtol = 0``.
+
+    ``dual0 = (p, q)`` starts from that projected dual instead of zero with the momentum restarted (the build's warm-dual
+    variant; NOT the reference's algorithm); ``return_dual`` also returns the final ``(p, q)``.
     """
     x = np.asarray(x)
     dt = x.dtype
@@ -452,10 +464,15 @@ def tv_prox_fgp(x, gamma, niter, step=0.125, betas=None, rtol=0.0, momentum="unl
     if betas is None:
         betas = fgp_betas(niter, momentum)
     betas = np.asarray(betas, dtype=dt)
-    rr = np.zeros_like(x)
-    ss = np.zeros_like(x)
-    p = np.zeros_like(x)
-    q = np.zeros_like(x)
+    if dual0 is None:
+        rr = np.zeros_like(x)
+        ss = np.zeros_like(x)
+        p = np.zeros_like(x)
+        q = np.zeros_like(x)
+    else:
+        p = np.array(dual0[0], dtype=dt)
+        q = np.array(dual0[1], dtype=dt)
+        rr, ss = p.copy(), q.copy()
     prev_obj = None
     one = dt.type(1)
     for k in range(niter):
@@ -477,7 +494,8 @@ def tv_prox_fgp(x, gamma, niter, step=0.125, betas=None, rtol=0.0, momentum="unl
         rr = pn + betas[k] * (pn - p)
         ss = qn + betas[k] * (qn - q)
         p, q = pn, qn
-    return x - gamma * div2d(rr, ss)
+    out = x - gamma * div2d(rr, ss)
+    return (out, (p, q)) if return_dual else out
 
 
 class TV(_Prox):
@@ -717,8 +735,13 @@ def myula_step(x, y, h, offset, sigma_f, tau, gamma, prior, xi, mask=None):
         thr = t * dt.type(prior["sigma"])
         px = np.sign(x) * np.maximum(np.abs(x) - thr, 0)
     elif kind == "tv":
-        px = tv_prox_fgp(x, float(t) * prior["sigma"], prior["niter"], step=prior.get("step", 0.125),
-                         betas=prior.get("betas"), momentum=prior.get("momentum", "unlocbox"))
+        if prior.get("warm"):     # warm-dual variant: prior["dual"] carries (p, q) between calls (updated in place in the dict)
+            px, prior["dual"] = tv_prox_fgp(x, float(t) * prior["sigma"], prior["niter"], step=prior.get("step", 0.125),
+                                            betas=prior.get("betas"), momentum=prior.get("momentum", "unlocbox"),
+                                            dual0=prior.get("dual"), return_dual=True)
+        else:
+            px = tv_prox_fgp(x, float(t) * prior["sigma"], prior["niter"], step=prior.get("step", 0.125),
+                             betas=prior.get("betas"), momentum=prior.get("momentum", "unlocbox"))
     elif kind == "haar":
         px = haar_l1_prox(x, float(t) * prior["sigma"], prior.get("levels", 3))
     elif kind == "none":

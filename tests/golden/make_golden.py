@@ -45,6 +45,9 @@ sys.path.insert(0, ROOT)
 from oracle import lmc_oracle as O  # noqa: E402
 
 
+HONOUR_RTOL = [False]
+
+
 def _mod(name, **attrs):
     m = types.ModuleType(name)
     m.__dict__.update(attrs)
@@ -67,8 +70,10 @@ def install_standins():
          get_module_name=lambda m: "numpy", to_numpy=lambda x: x)
     # L2_ncvx_tv.__init__ instantiates pyproximal.L1 / pyproximal.TV (algs.py:166,169):
     # hand it the oracle's restatements of those two operators.
+    # TV: rtol forced to 0 for the main fixtures (the device's fixed-count semantics); gen_algs_rtol() flips HONOUR_RTOL to
+    # generate the second set in which the inner prox keeps the early exit the reference asks for (algs.py:169: rtol = 1e-4)
     _mod("pyproximal", ProxOperator=ProxOperator, L1=O.L1,
-         TV=lambda dims, sigma, niter, rtol: O.TV(dims, sigma, niter, rtol=0.0))
+         TV=lambda dims, sigma, niter, rtol: O.TV(dims, sigma, niter, rtol=(rtol if HONOUR_RTOL[0] else 0.0)))
     _mod("pyproximal.ProxOperator", _check_tau=lambda f: f)
     _mod("fastprogress", progress_bar=lambda it, *a, **k: it)
     _mod("fire", Fire=lambda *a, **k: None)
@@ -252,6 +257,38 @@ def gen_algs(out):
     np.savez_compressed(out, **d)
 
 
+def gen_algs_rtol(out):
+    """Second golden set: the reference's loops with the TV prox keeping upstream's early exit (``rtol = 1e-4``, pyproximal's
+    default, which ``TV(dims, sigma, niter=niter_tv)`` at prox_lmc_deconv.py:122 does not override, and which algs.py:169 passes on
+    explicitly) -- through the oracle's ``rtol`` path.  Stored next to the rtol = 0 run of the same seeds so that the divergence the
+    device's fixed-count prox introduces is on record (tests/test_oracle_golden.py prints and bounds it)."""
+    A = load_ref("algs")
+    d = {}
+    sigma, tau_reg = 0.75, 0.3
+    gamma_myula = sigma ** 2
+    tau_myula = 0.2 * gamma_myula
+    ny, nx, k, seed = 32, 32, 5, 0
+    img, h, Hop, y = deconv_problem(ny, nx, k, sigma, seed)
+    d["img"], d["h"], d["y"], d["meta"] = img, h, y, np.array([ny, nx, k, seed])
+    x0 = np.zeros(ny * nx)
+    for tag, rtol in (("rtol0", 0.0), ("rtol1e-4", 1e-4)):
+        HONOUR_RTOL[0] = rtol > 0
+        l2 = O.L2(Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, niter=50, warm=True)
+        d[f"myula_tv_{tag}"] = A.MoreauYosidaUnadjustedLangevin(l2, O.TV((ny, nx), sigma=tau_reg, niter=10, rtol=rtol), tau=tau_myula,
+                                                                gamma=gamma_myula, x0=x0, niter=200, seed=seed)[::10]
+        me = A.L2_ncvx_tv(dims=(ny, nx), Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=15.0, isotropic=True,
+                          niter=50, rtol=1e-4, warm=True)
+        xt = (img + np.random.default_rng(100).normal(0, 5.0, img.shape)).ravel()
+        d[f"ncvx_me_grad_{tag}"] = me.grad(xt.copy())
+        d[f"myula_me_tv_{tag}"] = A.MoreauYosidaUnadjustedLangevin(
+            me, O.TV((ny, nx), sigma=tau_reg, niter=10, rtol=rtol), tau=tau_myula, gamma=gamma_myula, x0=x0, niter=20, seed=seed)[::5]
+    HONOUR_RTOL[0] = False
+    d["ncvx_x"] = xt
+    d["params"] = np.array([sigma, tau_reg, tau_myula, gamma_myula])
+    d["versions"] = versions()
+    np.savez_compressed(out, **d)
+
+
 CHAMBOLLE = r'''
 import sys, numpy as np
 from skimage.restoration import denoise_tv_chambolle
@@ -309,6 +346,7 @@ if __name__ == "__main__":
     gen_toy(os.path.join(HERE, "toy.npz"))
     gen_prox(os.path.join(HERE, "prox.npz"))
     gen_algs(os.path.join(HERE, "algs.npz"))
+    gen_algs_rtol(os.path.join(HERE, "algs_rtol.npz"))
     gen_chambolle(os.path.join(HERE, "tv_chambolle.npz"))
     gen_pywt(os.path.join(HERE, "haar_pywt.npz"))
     for f in sorted(os.listdir(HERE)):

@@ -202,27 +202,29 @@ def test_multi_step_call_equals_single_steps(la):
     np.testing.assert_array_equal(a.get_state().cpu().numpy(), b.get_state().cpu().numpy())
 
 
-def test_stream_and_tile_variants_agree(la):
-    """Same inputs through both step kernels (different on-chip schedules of the same arithmetic)."""
+def test_split_and_tile_variants_agree(la):
+    """Same inputs through different step kernels (different on-chip schedules of the same arithmetic), each sampler carrying its
+    OWN variant (lmc_problem.step_variant, ABI 2): handles with different variants live side by side, the library default untouched."""
     rng = np.random.default_rng(2)
+    assert la.set_step_variant("auto") == "auto"
     for shape, k, niter in [((64, 64), 5, 10), ((100, 200), 7, 4), ((37, 130), 6, 3), ((512, 512), 5, 10),
-                            ((40, 256), 5, 12), ((9, 33), 3, 1)]:
+                            ((40, 256), 5, 12), ((9, 33), 3, 1), ((40, 96), 5, 9)]:
         img, h, y = synth(*shape, seed=1, k=k)
         pf = la.L2(Op=la.Convolve2D(shape, h, offset=(k // 2, k // 2)), b=y, sigma=1 / 0.75 ** 2)
         pg = la.TV(shape, sigma=0.3, niter=niter)
         x0 = img[None] + rng.normal(0, 10, (2,) + shape)
+        smps = {v: la.MYULASampler(pf, pg, shape, n_chains=2, tau=0.1125, gamma=0.5625, seed=5, variant=v) for v in ("tile", "split")}
         outs = {}
-        for v in ("tile", "stream", "split"):
-            la.set_step_variant(v)
-            smp = la.MYULASampler(pf, pg, shape, n_chains=2, tau=0.1125, gamma=0.5625, seed=5)
+        for v, smp in smps.items():          # interleaved: each handle keeps its own kernel
             smp.set_state(x0)
-            smp.step(3)
+            smp.step(1)
+        for v, smp in smps.items():
+            smp.step(2)
             outs[v] = smp.get_state().cpu().numpy()
             assert v in smp.kernel_name
             smp.close()
-        assert rel(outs["stream"], outs["tile"]) < 2e-6, (shape, rel(outs["stream"], outs["tile"]))
         assert rel(outs["split"], outs["tile"]) < 2e-6, (shape, rel(outs["split"], outs["tile"]))
-    # other data terms / priors through all three kernels
+    # other data terms / priors through all kernels that cover them
     shape = (45, 150)
     img, h, y = synth(*shape, seed=3)
     mask = (rng.uniform(size=shape) < 0.5).astype(np.float64)
@@ -232,29 +234,33 @@ def test_stream_and_tile_variants_agree(la):
              (la.L2(Op=la.Convolve2D(shape, h), b=y, sigma=1.7), None)]
     for pf, pg in cases:
         outs = {}
-        variants = ("tile", "stream", "split") if isinstance(pg, la.TV) else ("tile", "stream", "split", "point")
+        variants = ("tile", "split") if isinstance(pg, la.TV) else ("tile", "split", "point")
         for v in variants:
-            la.set_step_variant(v)
-            smp = la.MYULASampler(pf, pg, shape, n_chains=3, tau=0.1125, gamma=0.5625, seed=8, chain_offset=5)
+            smp = la.MYULASampler(pf, pg, shape, n_chains=3, tau=0.1125, gamma=0.5625, seed=8, chain_offset=5, variant=v)
             smp.set_state(img)
             smp.step(4)
             outs[v] = smp.get_state().cpu().numpy()
             smp.close()
-        assert rel(outs["stream"], outs["tile"]) < 2e-6 and rel(outs["split"], outs["tile"]) < 2e-6
+        assert rel(outs["split"], outs["tile"]) < 2e-6
         if "point" in outs:
             assert rel(outs["point"], outs["tile"]) < 2e-6
-    # a configuration the streaming kernel does not cover (K = 16): forcing it is an error, the default falls back
+    # a configuration the split kernel does not cover (K = 16): forcing it is an error, the default falls back
     shape = (40, 96)
     img, h, y = synth(*shape, seed=1)
     pf = la.L2(Op=la.Convolve2D(shape, h), b=y, sigma=1 / 0.75 ** 2)
     pg = la.TV(shape, sigma=0.3, niter=16)
-    la.set_step_variant("stream")
-    smp = la.MYULASampler(pf, pg, shape, n_chains=1, tau=0.1125, gamma=0.5625)
+    smp = la.MYULASampler(pf, pg, shape, n_chains=1, tau=0.1125, gamma=0.5625, variant="split")
     with pytest.raises(la.LMCError, match="no step-kernel variant"):
         smp.step(1)
-    la.set_step_variant("auto")
+    smp.close()
+    smp = la.MYULASampler(pf, pg, shape, n_chains=1, tau=0.1125, gamma=0.5625)
     smp.step(1)
     assert "tile" in smp.kernel_name
+    smp.close()
+    # the one-group "stream" kernel of ABI 1 is gone: asking for it is an error, not a silent substitution
+    with pytest.raises(ValueError):
+        la.set_step_variant("stream")
+    assert la._dev.lib().lmc_set_step_variant(2) < 0
 
 
 def test_wide_images_use_tiled_kernels(la, variant):
