@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps; the median is reported (SURVEY 8(d))")
     ap.add_argument("--tv-warm", action="store_true",
                     help="warm-dual TV (SURVEY 8(d) C3 variant; build extension): carry the TV dual between MYULA iterations, "
-                         "--tv-iters in {1, 2, 3, 9, 10} per iteration (+16 B/px of HBM traffic, quoted as `actual_bytes_per_launch`)")
+                         "--tv-iters in {1, 2, 3} per iteration (+16 B/px of HBM traffic, quoted as `actual_bytes_per_launch`)")
     ap.add_argument("--tv-lagged", action="store_true", help="TV prox after tv_iters - 1 dual updates (lmc_problem.tv_lagged_output)")
     ap.add_argument("--no-hbm-probe", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -119,7 +119,7 @@ typedef struct lmc_problem {
    * (lmc_set_cg_tolerance, itself 1e-6 unless changed), > 0 explicit, < 0 disabled (always all iterations, CG). */
   float implicit_tol;
   /* MYULA samplers only (build extension; NOT the reference's algorithm, whose pyproximal.TV.prox starts every call from a zero dual):
-   * != 0 carries the projected TV dual (p, q) from one MYULA iteration to the next -- tv_niter in {1, 2, 3, 9, 10} dual iterations per
+   * != 0 carries the projected TV dual (p, q) from one MYULA iteration to the next -- tv_niter in {1, 2, 3} dual iterations per
    * MYULA iteration, momentum restarted, +16 B per pixel and iteration of HBM traffic for the dual field.  SURVEY section 8(d) "K in
    * {1,3} warm-dual reported too".  lmc_sampler_set_state resets the dual to zero.  Needs the full-width pipeline kernel
    * (132 <= W <= 512, separable blur / pointwise / no data term), otherwise LMC_E_UNSUPPORTED. */

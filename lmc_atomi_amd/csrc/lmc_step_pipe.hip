@@ -40,10 +40,10 @@ int pipe_links(const StepArgs& a) {
 bool pipe_supported(const StepArgs& a) { return pipe_links(a) == 1; }
 
 // warm-started prox: the projected dual (p, q) of the previous MYULA iteration comes in through a.tv_in and the new one leaves through
-// a.tv_out ([C][2][H][W] each, never NULL), a.tv.niter in {1, 2, 3, 9, 10} dual iterations per MYULA iteration
+// a.tv_out ([C][2][H][W] each, never NULL), a.tv.niter in {1, 2, 3} dual iterations per MYULA iteration
 bool pipe_warm_supported(const StepArgs& a) {
   const int n = a.tv.niter;
-  if (!(n == 1 || n == 2 || n == 3 || n == 9 || n == 10)) return false;
+  if (!(n == 1 || n == 2 || n == 3)) return false;
   return pipe_geometry_ok(a);
 }
 

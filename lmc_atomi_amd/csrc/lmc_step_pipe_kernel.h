@@ -17,6 +17,9 @@
 
 namespace lmc {
 
+#ifndef LMC_WARM_MIN_WAVES
+#define LMC_WARM_MIN_WAVES 1
+#endif
 #ifdef LMC_EXP_NOBARRIER   // timing experiment: waves free-run (results are wrong)
 #define PIPE_TICK_SYNC() do {} while (0)
 #else
@@ -174,8 +177,11 @@ __device__ __forceinline__ void gload_raw(float (&dst)[PXL], const float* __rest
 // KT = 0: no data term (pure prox, or t = 0).  CHAIN: the launch is one link of a chain of launches that together run more than K
 // dual iterations: stage 1 starts from the dual state A.tv_in of the previous link ([C][4][H][W]: rr, ss, p, q; NULL = zeros), the last
 // stage's state goes to A.tv_out (NULL = not stored), and with A.tv_state_only the combine / store of x_out is skipped.
-template <int K, int PXL, int KT, bool CHAIN = false>
-__global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2) void myula_step_pipe_kernel(const StepArgs A) {
+// WARM (with CHAIN): the state is the two-field projected dual carried between MYULA iterations (A.tv_warm) instead of the four-field
+// link state -- a template parameter because the L wave's prefetch registers for the state rows set the kernel's VGPR count.
+template <int K, int PXL, int KT, bool CHAIN = false, bool WARM = false>
+__global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM ? LMC_WARM_MIN_WAVES : 1) : 2) void myula_step_pipe_kernel(const StepArgs A) {
+  static_assert(!WARM || CHAIN, "the warm dual uses the state hand-over of the chained launches");
   using G = PipeGeom<K>;
   using L = PipeLds<K, PXL, CHAIN>;
   constexpr int D = G::D, E = G::E, RB = G::RB, NT = G::NT, BW = L::BW, HW = KT > 0 ? (KT - 1) / 2 : 0;
@@ -264,16 +270,16 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2
     // chained launch: the dual state rows for stage 1, fetched two ticks ahead (row t - E - 1 is published at tick t)
     // (warm dual, A.tv_warm: the state is the projected dual (p, q) of the previous MYULA iteration, two fields; it enters stage 1 as
     // both the extrapolated and the projected iterate -- the momentum restarts, beta_1 = 0)
-    float spre[CHAIN ? 2 : 1][CHAIN ? 4 : 1][CHAIN ? PXL : 1];
-    const int nsf = CHAIN ? (A.tv_warm ? 2 : 4) : 0;          // fields per pixel of the incoming state
+    constexpr int nsf = CHAIN ? (WARM ? 2 : 4) : 0;           // fields per pixel of the incoming state
+    float spre[CHAIN ? 2 : 1][CHAIN ? nsf : 1][CHAIN ? PXL : 1];
     const float* const sin = CHAIN && A.tv_in ? A.tv_in + (size_t)chain * nsf * img : nullptr;
     if constexpr (CHAIN) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int rs = u - E - 1;
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
-          if (f < nsf) gload_row<PXL>(spre[u][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H);
+        for (int f = 0; f < nsf; ++f)
+          gload_row<PXL>(spre[u][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H);
       }
     }
     double facc = 0.0;        // sum of squared residuals (A.f_out)
@@ -297,11 +303,11 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2
       if constexpr (CHAIN) {   // dual state row t - E - 1 of the previous link -> stage 1's hand-off slot P (read next tick)
         float* hb = lds + L::o_hand0 + P * 4 * BW;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) if (f < nsf) prow_store<PXL>(hb + f * BW, lane, spre[P][f]);
+        for (int f = 0; f < nsf; ++f) prow_store<PXL>(hb + f * BW, lane, spre[P][f]);
         const int rs = t + 2 - E - 1;
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
-          if (f < nsf) gload_row<PXL>(spre[P][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H);
+        for (int f = 0; f < nsf; ++f)
+          gload_row<PXL>(spre[P][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H);
       }
       if constexpr (KT > 0) {
       const int i = t + 1 - D + (KT - 1);       // blur input row (<= t-1: published in an earlier tick)
@@ -411,9 +417,9 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2
     const float cr_last = (c0 + PXL - 1 == W - 1) ? 0.f : cstep;     // no horizontal difference across column W-1
     float* const hout = lds + L::o_hand + (wave - 1) * 8 * BW;       // this wave's hand-off [2][4][BW] ([2][2][BW] for the last one if CHAIN)
     const bool from_state = CHAIN && wave == 1 && A.tv_in != nullptr;
-    const bool warm = CHAIN && A.tv_warm;
+    constexpr bool warm = WARM;
     const float* const hin = from_state ? lds + L::o_hand0 : hout - 8 * BW;   // the previous wave's / the previous link's state
-    const int nof = warm ? 2 : 4;                                    // fields per pixel of the outgoing state
+    constexpr int nof = warm ? 2 : 4;                                // fields per pixel of the outgoing state
     float* const sout = CHAIN && wave == NT && A.tv_out ? A.tv_out + (size_t)chain * nof * img : nullptr;
     constexpr int NP = PXL / 2;
     DualRow<NP> inb[2], o1[2];
@@ -656,9 +662,9 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? 1 : 2
 template <int K, int PXL, int KT, bool CHAIN = false>
 static constexpr size_t pipe_lds_bytes() { return sizeof(float) * (size_t)PipeLds<K, PXL, CHAIN>::total; }
 
-template <int PXL, int KT, bool CHAIN, int K = 10>
+template <int PXL, int KT, bool CHAIN, int K = 10, bool WARM = false>
 static hipError_t pipe_launch_one(const StepArgs& a, hipStream_t st) {
-  auto kern = myula_step_pipe_kernel<K, PXL, KT, CHAIN>;
+  auto kern = myula_step_pipe_kernel<K, PXL, KT, CHAIN, WARM>;
   constexpr size_t lb = pipe_lds_bytes<K, PXL, KT, CHAIN>();
   static bool attr_set[64] = {};        // per device: the attribute belongs to the function's code object on that device
   int dev = 0;
@@ -674,19 +680,20 @@ static hipError_t pipe_launch_one(const StepArgs& a, hipStream_t st) {
 }
 
 // one launch with K dual iterations: blur taps 5 / 7 / none (KT), 8 pixels per lane above 256 columns, else 4
-template <int K, bool CHAIN>
+template <int K, bool CHAIN, bool WARM = false>
 static hipError_t pipe_dispatch_k(const StepArgs& a, int KT, hipStream_t st) {
   if (a.W > 256) {
-    if (KT == 5) return pipe_launch_one<8, 5, CHAIN, K>(a, st);
-    if (KT == 7) return pipe_launch_one<8, 7, CHAIN, K>(a, st);
-    return pipe_launch_one<8, 0, CHAIN, K>(a, st);
+    if (KT == 5) return pipe_launch_one<8, 5, CHAIN, K, WARM>(a, st);
+    if (KT == 7) return pipe_launch_one<8, 7, CHAIN, K, WARM>(a, st);
+    return pipe_launch_one<8, 0, CHAIN, K, WARM>(a, st);
   }
-  if (KT == 5) return pipe_launch_one<4, 5, CHAIN, K>(a, st);
-  if (KT == 7) return pipe_launch_one<4, 7, CHAIN, K>(a, st);
-  return pipe_launch_one<4, 0, CHAIN, K>(a, st);
+  if (KT == 5) return pipe_launch_one<4, 5, CHAIN, K, WARM>(a, st);
+  if (KT == 7) return pipe_launch_one<4, 7, CHAIN, K, WARM>(a, st);
+  return pipe_launch_one<4, 0, CHAIN, K, WARM>(a, st);
 }
 
-// lmc_step_pipe_chain.hip: the CHAIN instantiations (dual state in / out through HBM), K = 1, 2, 3, 9, 10
+// lmc_step_pipe_chain.hip: the CHAIN instantiations (dual state in / out through HBM): links of a chained launch (K = 9, 10) and the
+// warm-started prox (a.tv_warm: K = 1, 2, 3)
 hipError_t pipe_dispatch_chain(const StepArgs& a, int K, int KT, hipStream_t st);
 
 }  // namespace lmc

@@ -298,7 +298,7 @@ class TV(ProxOperator):
       updates depends on the loop bound of the un-pinned upstream version; ``False`` (default) = ``niter`` updates,
       ``True`` = ``niter - 1`` (one pipeline stage fewer).
     * ``warm`` (build extension, MYULA samplers only): carry the projected dual from one MYULA iteration to the next, ``niter``
-      in {1, 2, 3, 9, 10} updates per MYULA iteration ("K in {1,3} warm-dual")."""
+      in {1, 2, 3} updates per MYULA iteration ("K in {1,3} warm-dual")."""
 
     def __init__(self, dims, sigma=1.0, niter=10, rtol=0.0, step=0.125, momentum="unlocbox", lagged_output=False, warm=False):
         super().__init__(None, False)

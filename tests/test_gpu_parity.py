@@ -206,7 +206,7 @@ def test_split_and_tile_variants_agree(la):
     """Same inputs through different step kernels (different on-chip schedules of the same arithmetic), each sampler carrying its
     OWN variant (lmc_problem.step_variant, ABI 2): handles with different variants live side by side, the library default untouched."""
     rng = np.random.default_rng(2)
-    assert la.set_step_variant("auto") == "auto"
+    la.set_step_variant("auto")          # (the autouse fixture of this module restores its own setting afterwards)
     for shape, k, niter in [((64, 64), 5, 10), ((100, 200), 7, 4), ((37, 130), 6, 3), ((512, 512), 5, 10),
                             ((40, 256), 5, 12), ((9, 33), 3, 1), ((40, 96), 5, 9)]:
         img, h, y = synth(*shape, seed=1, k=k)
@@ -257,6 +257,7 @@ def test_split_and_tile_variants_agree(la):
     smp.step(1)
     assert "tile" in smp.kernel_name
     smp.close()
+    assert la.set_step_variant("auto") == "auto"       # per-handle variants never touched the library default
     # the one-group "stream" kernel of ABI 1 is gone: asking for it is an error, not a silent substitution
     with pytest.raises(ValueError):
         la.set_step_variant("stream")
