@@ -297,7 +297,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "peak_measured": peak_measured,
                 "frac_of_measured": (achieved / peak_measured) if peak_measured else None,
-                "peak_measured_how": "lmc_hbm_copy_probe: 1 GiB read + 1 GiB written, float4 per lane, best of 3 after a warm-up, this process",
+                "peak_measured_how": "lmc_hbm_copy_probe: 1 GiB read + 1 GiB written, float4 per lane, best of 10 launch shapes x 3 passes, this process",
                 "traffic": traffic,
                 "launch_ms": per_launch_ms,
                 "launches": launches,

@@ -131,7 +131,7 @@ int lmc_version(void);                 /* LMC_ATOMI_ABI_VERSION of the loaded li
 const char* lmc_last_error(void);      /* thread-local; valid until the next failing call on this thread */
 int lmc_device_info(int* device, int* n_cu, size_t* lds_bytes, size_t* hbm_bytes);
 /* Measured HBM streaming bandwidth of the current device: a state-shaped copy (read `bytes`, write `bytes`, 16 B per lane), the best of
- * `reps` timed passes after one warm-up, in GB/s counting both directions -- the figure bench.py prints beside the 8 TB/s spec peak
+ * `reps` timed passes after one warm-up over ten launch shapes, in GB/s counting both directions -- the figure bench.py prints beside the 8 TB/s spec peak
  * (SURVEY section 8(d)).  Allocates and frees 2 x bytes of HBM; synchronises `stream`. */
 int lmc_hbm_copy_probe(size_t bytes, int32_t reps, float* gbs_out, void* stream);
 

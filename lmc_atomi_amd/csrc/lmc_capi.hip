@@ -567,15 +567,16 @@ int lmc_hbm_copy_probe(size_t bytes, int32_t reps, float* gbs_out, void* stream)
   if (e == hipSuccess) e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);
   float best = 0.f;
-  for (int r = 0; r < reps + 1 && e == hipSuccess; ++r) {   // the first pass warms up (page mapping, clocks)
-    e = hipEventRecord(e0, st);
-    if (e == hipSuccess) e = lmc::launch_hbm_copy_probe(x, y, n, st);
-    if (e == hipSuccess) e = hipEventRecord(e1, st);
-    if (e == hipSuccess) e = hipEventSynchronize(e1);
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    if (e == hipSuccess && r > 0 && ms > 0.f) best = fmaxf(best, (float)(2.0 * (double)n * sizeof(float) / ((double)ms * 1e-3) / 1e9));
-  }
+  for (int shape = 0; shape < lmc::hbm_copy_probe_shapes(); ++shape)     // launch shapes: what a plain copy reaches depends on them
+    for (int r = 0; r < reps + 1 && e == hipSuccess; ++r) {   // the first pass warms up (page mapping, clocks)
+      e = hipEventRecord(e0, st);
+      if (e == hipSuccess) e = lmc::launch_hbm_copy_probe(x, y, n, shape, st);
+      if (e == hipSuccess) e = hipEventRecord(e1, st);
+      if (e == hipSuccess) e = hipEventSynchronize(e1);
+      float ms = 0.f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+      if (e == hipSuccess && r > 0 && ms > 0.f) best = fmaxf(best, (float)(2.0 * (double)n * sizeof(float) / ((double)ms * 1e-3) / 1e9));
+    }
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
   if (x) (void)hipFree(x);

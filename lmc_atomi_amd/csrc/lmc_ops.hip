@@ -674,9 +674,30 @@ __global__ __launch_bounds__(256) void hbm_copy_probe_kernel(const float4* __res
   }
 }
 
-hipError_t launch_hbm_copy_probe(const float* x, float* y, size_t n_floats, hipStream_t st) {
-  hipLaunchKernelGGL(hbm_copy_probe_kernel, dim3(8192), dim3(256), 0, st, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y),
-                     n_floats / 4, 1.0f);
+// two independent 16-byte loads in flight per lane and iteration
+__global__ __launch_bounds__(256) void hbm_copy_probe2_kernel(const float4* __restrict__ x, float4* __restrict__ y, size_t n4, float a) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    float4 v = x[i], w = x[i + stride];
+    v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+    w.x *= a; w.y *= a; w.z *= a; w.w *= a;
+    y[i] = v;
+    y[i + stride] = w;
+  }
+  if (i < n4) { float4 v = x[i]; v.x *= a; v.y *= a; v.z *= a; v.w *= a; y[i] = v; }
+}
+
+// shape: 0..4 = grid-stride copy with 1024 << shape workgroups; 5..9 = the same grids with two loads in flight per lane
+int hbm_copy_probe_shapes() { return 10; }
+hipError_t launch_hbm_copy_probe(const float* x, float* y, size_t n_floats, int shape, hipStream_t st) {
+  const int grid = 1024 << (shape % 5);
+  if (shape < 5)
+    hipLaunchKernelGGL(hbm_copy_probe_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y),
+                       n_floats / 4, 1.0f);
+  else
+    hipLaunchKernelGGL(hbm_copy_probe2_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y),
+                       n_floats / 4, 1.0f);
   return hipGetLastError();
 }
 
