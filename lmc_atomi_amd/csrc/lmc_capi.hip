@@ -530,6 +530,14 @@ struct lmc_sampler {
   hipEvent_t ev_step = nullptr;              // "the step that wrote x[cur] is done" (recorded on the caller's stream)
   hipEvent_t ev_mom[2] = {nullptr, nullptr}; // "the reduction that reads x[i] is done" (recorded on the side stream)
   bool mom_pending[2] = {false, false};
+  // hipGraph replay of kGraphIters iterations at a time (small configurations, where launch gaps and the serial moment reduction
+  // are a large part of an iteration): step kernels on the caller's stream, the moment reduction of iteration k on a captured side
+  // branch under the step kernel of iteration k + 1; the Philox iteration word comes from device memory (StepArgs.iter_dev)
+  hipGraphExec_t gexec[2] = {nullptr, nullptr};   // by `cur` at the start of the block of iterations
+  uint32_t* iter_dev = nullptr;
+  hipStream_t gmain = nullptr, gside = nullptr;   // capture streams (the caller's stream may be the legacy default stream, which cannot capture)
+  std::vector<hipEvent_t> gev;
+  bool plain_done = false;      // at least one ordinary launch has happened (function attributes set, kernel known)
   std::vector<hipEvent_t> ev;   // pairs (begin, end) around each step-kernel launch of the last step() call
   bool timing = false;
   bool timed = false;
@@ -856,6 +864,11 @@ void lmc_sampler_destroy(lmc_sampler* s) {
   if (s->s2) (void)hipFree(s->s2);
   if (s->packed) (void)hipFree(s->packed);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : s->gev) (void)hipEventDestroy(e);
+  for (hipGraphExec_t g : s->gexec) if (g) (void)hipGraphExecDestroy(g);
+  if (s->gside) (void)hipStreamDestroy(s->gside);
+  if (s->gmain) (void)hipStreamDestroy(s->gmain);
+  if (s->iter_dev) (void)hipFree(s->iter_dev);
   if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
   if (s->ev_step) (void)hipEventDestroy(s->ev_step);
   for (hipEvent_t e : s->ev_mom) if (e) (void)hipEventDestroy(e);
@@ -930,6 +943,72 @@ static int sampler_update(lmc_sampler* s, const float* x_in, float* x_out, bool 
   return LMC_OK;
 }
 
+
+// ---- hipGraph replay of MYULA iterations (small configurations) -------------------------------------------------------------------
+constexpr int kGraphIters = 8;     // iterations per graph launch (even: the ping-pong buffers are back in place)
+
+static bool graph_wanted(const lmc_sampler* s) {
+  const char* env = getenv("LMC_GRAPH");          // 0 off, 1 on, unset: by size (read at every call: tests flip it)
+  // Opt-in (LMC_GRAPH=1).  Measured on ROCm 7.2 / MI355X at BASELINE config 2 (256 x 256 x 128, rows kernel 25 us + reduction 15.6 us): plain
+  // launches 40.2 us per iteration -- the queue is never empty, there are no launch gaps to recover -- graph replay 42.0 us (the side branch
+  // does not run under the next step kernel); what does help is the reduction on a second HIP stream (LMC_MOMENTS_OVERLAP, default for small
+  // configurations): 37.1 us.  Kept because the replay is exact (tests/test_gpu_graph.py) and may pay on another runtime.
+  return env && atoi(env) == 1;
+}
+
+// Captures kGraphIters iterations starting from buffer s->cur into an executable graph.
+static int build_graph(lmc_sampler* s) {
+  if (!s->iter_dev) {
+    HIP_TRY(hipMalloc(&s->iter_dev, sizeof(uint32_t)));
+    HIP_TRY(hipStreamCreateWithFlags(&s->gmain, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&s->gside, hipStreamNonBlocking));
+    s->gev.resize(2 * kGraphIters);
+    for (hipEvent_t& e : s->gev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const bool mom = s->moments != 0;
+  int cur = s->cur;
+  hipStream_t st = s->gmain;           // nothing runs here: the launches below are recorded, the graph is replayed on the caller's stream
+  HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  int rc = LMC_OK;
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < kGraphIters && e == hipSuccess; ++k) {
+    lmc::StepArgs A = s->base;
+    A.x_in = s->x[cur];
+    A.x_out = s->x[cur ^ 1];
+    A.iteration = (uint32_t)k;
+    A.iter_dev = s->iter_dev;
+    A.noise = nullptr;
+    sanitize_pointers(A);
+    if (mom && k >= 2) e = hipStreamWaitEvent(st, s->gev[2 * (k - 2) + 1], 0);     // this step overwrites what reduction k - 2 reads
+    const char* kname = nullptr;
+    if (e == hipSuccess) e = launch_step(A, variant_of(s->prob), st, &kname, s->tvstate[0], s->tvstate[1], s->pxbuf);
+    cur ^= 1;
+    if (mom && e == hipSuccess) {       // reduction of the new state on the side branch, under the next step kernel
+      e = hipEventRecord(s->gev[2 * k], st);
+      if (e == hipSuccess) e = hipStreamWaitEvent(s->gside, s->gev[2 * k], 0);
+      if (e == hipSuccess) e = lmc::launch_moments(s->x[cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, s->gside);
+      if (e == hipSuccess) e = hipEventRecord(s->gev[2 * k + 1], s->gside);
+    }
+  }
+  if (mom && e == hipSuccess) {         // join: the last two reductions (the earlier ones were waited for by later steps)
+    for (int k = kGraphIters - 2; k < kGraphIters && e == hipSuccess; ++k) e = hipStreamWaitEvent(st, s->gev[2 * k + 1], 0);
+  }
+  if (e == hipSuccess) e = lmc::launch_bump_u32(s->iter_dev, (uint32_t)kGraphIters, st);
+  hipGraph_t graph = nullptr;
+  const hipError_t e2 = hipStreamEndCapture(st, &graph);       // always end the capture, also after a failed launch
+  if (e != hipSuccess || e2 != hipSuccess) {
+    if (graph) (void)hipGraphDestroy(graph);
+    rc = fail(LMC_E_HIP, "graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return rc;
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return fail(LMC_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  s->gexec[s->cur] = exec;
+  return LMC_OK;
+}
+
 int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, void* stream) {
   if (!s) return fail(LMC_E_INVALID, "NULL sampler");
   DeviceGuard dg(s->device);
@@ -969,7 +1048,11 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     }
   }
   // LMC_MOMENTS_OVERLAP=1: run the moment reductions on a side stream under the following step kernel
-  static const bool want_overlap = [] { const char* e = getenv("LMC_MOMENTS_OVERLAP"); return e && atoi(e) != 0; }();
+  // default: on for small configurations (<= 32 Mi pixel-updates per iteration, e.g. BASELINE config 2 at 256 x 256 x 128: the 15 us
+  // reduction is 40 % of a serial iteration; measured 40.2 -> 37.1 us per iteration), off for large ones (the reduction then competes with
+  // the step kernel for HBM); LMC_MOMENTS_OVERLAP = 0 / 1 forces it
+  const char* ov_env = getenv("LMC_MOMENTS_OVERLAP");
+  const bool want_overlap = ov_env ? atoi(ov_env) != 0 : (long long)s->C * s->prob.H * s->prob.W <= (1LL << 25);
   static const int bg_wgs = [] { const char* e = getenv("LMC_MOMENTS_BG_WGS"); return e ? atoi(e) : 128; }();   // 0: the full-speed kernel
   bool overlap = want_overlap && s->moments && n_iters > 1;
   if (overlap && !s->side) {
@@ -981,7 +1064,29 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     HIP_TRY(hipEventCreateWithFlags(&s->ev_step, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&s->ev_mom[i], hipEventDisableTiming));
   }
+  // graph replay: whole blocks of kGraphIters iterations whose every iteration is kept by the moment accumulators (or none is)
+  const bool graph_ok = !s->timing && (!overlap || (getenv("LMC_GRAPH") && atoi(getenv("LMC_GRAPH")) == 1)) && !noise_dev && s->noise_mode != LMC_NOISE_INJECTED && s->prob.ncvx_kind != LMC_NCVX_ME_TV &&
+                        !s->tvwarm[0] && (!s->moments || s->thin == 1) && graph_wanted(s);
+  bool graph_enabled = false;
   for (int k = 0; k < n_iters; ++k) {
+    if (graph_ok && s->plain_done && n_iters - k >= kGraphIters && (!s->moments || s->iteration >= s->burn_in) &&
+        (s->kernel_name == "myula_step_rows_kernel" || s->kernel_name == "myula_step_block_kernel" || s->kernel_name == "myula_step_pipe_kernel")) {
+      if (!s->gexec[s->cur]) { int rc = build_graph(s); if (rc) return rc; }
+      if (!graph_enabled) {             // the device-side iteration base of this call
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s->iter_dev), (int)(uint32_t)s->iteration, 1, st));
+        graph_enabled = true;
+      }
+      for (int i = 0; i < 2; ++i)         // reductions still running on the side stream read buffers the replay overwrites
+        if (s->mom_pending[i]) { HIP_TRY(hipStreamWaitEvent(st, s->ev_mom[i], 0)); s->mom_pending[i] = false; }
+      HIP_TRY(hipGraphLaunch(s->gexec[s->cur], st));
+      s->iteration += kGraphIters;
+      if (s->moments) s->count += (uint64_t)s->C * kGraphIters;
+      s->last_launches += kGraphIters;
+      k += kGraphIters - 1;
+      continue;
+    }
+    if (graph_enabled) {   // plain launches after graph replays take their iteration word by value again: nothing to do (iter_dev is unused)
+    }
     lmc::StepArgs A = s->base;
     A.x_in = s->x[s->cur];
     A.x_out = s->x[s->cur ^ 1];
@@ -1013,6 +1118,7 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no step-kernel variant covers this configuration");
     HIP_TRY(e);
     if (kname) s->kernel_name = kname;
+    s->plain_done = true;
     if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * k + 1], st));
     s->cur ^= 1;
     if (s->moments && s->iteration >= s->burn_in && (s->iteration - s->burn_in) % s->thin == 0) {

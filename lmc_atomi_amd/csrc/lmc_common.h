@@ -41,7 +41,9 @@ struct StepArgs {
   int noise_mode;
   const float* noise;        // [C][H][W] of this iteration (injected)
   uint32_t key0, key1;       // Philox key = seed
-  uint32_t iteration;        // Philox counter word 1
+  uint32_t iteration;        // Philox counter word 1 (+ *iter_dev when that is set)
+  const uint32_t* iter_dev;  // rows / block / pipe kernels: device-resident iteration base added to `iteration` -- lets a captured hipGraph of
+                             // iterations be replayed (kernel arguments are frozen in a graph; the counter word must advance)
   uint32_t chain_offset;     // global id of chain 0 (counter word 2 = chain_offset + c)
   const float* x_in;
   float* x_out;

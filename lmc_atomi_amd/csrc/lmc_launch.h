@@ -36,6 +36,7 @@ hipError_t launch_moments(const float* x, int C, int H, int W, double* s1, doubl
 hipError_t launch_moments_bg(const float* x, int C, int H, int W, double* s1, double* s2, int n_wg, hipStream_t st);
 hipError_t launch_energies(const float* x, int64_t n_img, const EnergyArgs& E, double* f_out, double* g_out,
                            hipStream_t st);
+hipError_t launch_bump_u32(uint32_t* p, uint32_t by, hipStream_t st);
 int hbm_copy_probe_shapes();
 hipError_t launch_hbm_copy_probe(const float* x, float* y, size_t n_floats, int shape, hipStream_t st);
 hipError_t launch_noise(float* out, int C, int H, int W, uint32_t key0, uint32_t key1, uint32_t iteration,

@@ -701,4 +701,11 @@ hipError_t launch_hbm_copy_probe(const float* x, float* y, size_t n_floats, int 
   return hipGetLastError();
 }
 
+// *p += by (one thread): the device-side iteration base of a replayed hipGraph of MYULA iterations
+__global__ void bump_u32_kernel(uint32_t* p, uint32_t by) { *p += by; }
+hipError_t launch_bump_u32(uint32_t* p, uint32_t by, hipStream_t st) {
+  hipLaunchKernelGGL(bump_u32_kernel, dim3(1), dim3(1), 0, st, p, by);
+  return hipGetLastError();
+}
+
 }  // namespace lmc

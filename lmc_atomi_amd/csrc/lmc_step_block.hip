@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
     if (P.noise_mode == LMC_NOISE_PHILOX) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        quad_normals(P.key0, P.key1, P.iteration, P.chain_offset + chain, (uint32_t)(by * 2 + q) * (uint32_t)W + (uint32_t)(bx * 8 + j), nz[j]);
+        quad_normals(P.key0, P.key1, P.iteration + (P.iter_dev ? *P.iter_dev : 0u), P.chain_offset + chain, (uint32_t)(by * 2 + q) * (uint32_t)W + (uint32_t)(bx * 8 + j), nz[j]);
         if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two Philox calls in flight, not eight: their temporaries decide the occupancy
       }
     }

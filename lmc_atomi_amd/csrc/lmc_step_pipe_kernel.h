@@ -523,6 +523,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     // In the tick of row 4q + NI the normals of pixels NI*PXL/4 .. of quad q + 1 are drawn into the other half of the slab
     // (spread evenly over the ticks: a burst every 4th tick would stall every wave at the barrier).
     float* const slab = lds + L::o_slab + lane;        // normal (row q of the quad, pixel k) at slab[(q*PXL + k)*64]
+    const uint32_t iter = A.iteration + (A.iter_dev ? *A.iter_dev : 0u);     // uniform; graph replays advance *iter_dev
     auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
       constexpr int U = decltype(uu)::value;
       constexpr int NI = ((U - D) % 4 + 4) % 4;        // == o & 3  (t = 4m + U)
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
           for (int kk = 0; kk < PXL / 4; ++kk) {
             const int k = NI * (PXL / 4) + kk;
             float n4[4];
-            quad_normals(A.key0, A.key1, A.iteration, A.chain_offset + (uint32_t)chain, (uint32_t)qn * (uint32_t)W + (uint32_t)(c0 + k), n4);
+            quad_normals(A.key0, A.key1, iter, A.chain_offset + (uint32_t)chain, (uint32_t)qn * (uint32_t)W + (uint32_t)(c0 + k), n4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) sl[(q * PXL + k) * 64] = n4[q];
           }

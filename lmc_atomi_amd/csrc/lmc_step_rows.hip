@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   float* __restrict__ xout = P.x_out + (size_t)chain * img;
   const float* __restrict__ uv = P.blur.h;              // u[0..KT) then v[0..KT) at h[kMaxBlur..], centred, zero padded
   const int i_first = r0 - LAG;
+  const uint32_t iter = P.iteration + (P.iter_dev ? *P.iter_dev : 0u);      // uniform scalar load; graph replays advance *iter_dev
 
   // 8 px / lane: the 32 normals of a quad row-group wait in a wave-private LDS slab (each lane reads back only what it
   // wrote, so no barrier) instead of 32 VGPRs -- the register file is the limit at 2 waves / SIMD.
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
 #pragma unroll
             for (int k = 0; k < PXL; ++k) {
               float n4[4];
-              quad_normals(P.key0, P.key1, P.iteration, P.chain_offset + (uint32_t)chain,
+              quad_normals(P.key0, P.key1, iter, P.chain_offset + (uint32_t)chain,
                            (uint32_t)(o >> 2) * (uint32_t)W + (uint32_t)(c0 + k), n4);
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
