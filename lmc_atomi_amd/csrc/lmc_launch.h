@@ -84,6 +84,11 @@ hipError_t ulpda_finish_philox(float* x, float* xhat, const float* u, int64_t C,
                                uint32_t key1, uint32_t iteration, uint32_t chain_offset, hipStream_t st);
 hipError_t ulpda_finish(float* x, float* xhat, const float* u, const float* xi, int64_t C, int H, int W, float s, float theta,
                         hipStream_t st);
+// finish + dual update in one row-streaming pass (gfirst = false; xhat stays in registers)
+bool ulpda_finish_dual_supported(int H, int W);
+hipError_t ulpda_finish_dual(const float* x, float* xnew, const float* u, float* y, const float* xi, int64_t C, int H, int W, float s, float theta, float mu,
+                             float radius, int iso, int philox, uint32_t key0, uint32_t key1, uint32_t iteration, uint32_t chain_offset,
+                             hipStream_t st);
 hipError_t cg_dot(const float* p, const float* q, int64_t C, size_t img, double* pq, const int* done, hipStream_t st);
 hipError_t cg_init(const float* rhs, const float* q, float* r, float* p, int64_t C, size_t img, double* rs, double* b2, hipStream_t st);
 hipError_t cg_update(float* u, float* r, const float* p, const float* q, int64_t C, size_t img, const double* rs, const double* pq,

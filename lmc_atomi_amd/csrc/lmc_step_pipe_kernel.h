@@ -440,10 +440,20 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     auto emit = [&](const DualRow<NP>& out, const int P, const int brow) __attribute__((always_inline)) {
       if (!CHAIN || wave < NT) {
         float* hb = hout + P * 4 * BW;
+#ifdef LMC_EXP_NO_HSTORE     // timing experiment: the hand-off stores never execute (results are wrong), the arithmetic stays alive
+        if (A.tv.niter == 12345)
+#endif
+        {
         pairs_store<NP>(hb, lane, out.rr);
         pairs_store<NP>(hb + BW, lane, out.ss);
+#ifdef LMC_EXP_HALF_HSTORE   // timing experiment: half the hand-off stores
+        if (A.tv.niter == 12345)
+#endif
+        {
         pairs_store<NP>(hb + 2 * BW, lane, out.p);
         pairs_store<NP>(hb + 3 * BW, lane, out.q);
+        }
+        }
       } else {
         float* hb = hout + P * 2 * BW;                   // last boundary of a chained launch: rr, ss for the final primal step ...
         pairs_store<NP>(hb, lane, out.rr);
@@ -472,6 +482,24 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
       constexpr int P = decltype(uu)::value & 1;
       const int a2 = t - E - 2 * k2, a1 = t - E - 2 * k1;
+#ifdef LMC_EXP_EARLY_HANDOFF
+      // the hand-off rows for stage k1 (written by the previous wave last tick) are requested before stage k2's arithmetic, which needs
+      // registers only: their LDS latency hides behind it instead of stalling the wave between the two stages
+      if constexpr (!FIRST) {
+        if (k1 > 1 || from_state) {
+          const float* hb = hin + (P ^ 1) * 4 * BW;
+          pairs_load<NP>(inb[P].rr, hb, lane);
+          pairs_load<NP>(inb[P].ss, hb + BW, lane);
+          if (from_state && warm) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { inb[P].p[k] = inb[P].rr[k]; inb[P].q[k] = inb[P].ss[k]; }
+          } else {
+            pairs_load<NP>(inb[P].p, hb + 2 * BW, lane);
+            pairs_load<NP>(inb[P].q, hb + 3 * BW, lane);
+          }
+        }
+      }
+#endif
       if constexpr (!SINGLE) {   // stage k2 on row a2: inputs are this wave's stage k1, one tick (row a2) and two ticks (row a2-1) old
         const float cdown = ((unsigned)(a2 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
         DualRow<NP> out;
@@ -479,6 +507,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
         emit(out, P, a2 - 1);
       }
       {   // stage k1 on row a1: inputs from the previous wave's hand-off (row a1) and the one read a tick earlier (row a1-1)
+#ifndef LMC_EXP_EARLY_HANDOFF
         if constexpr (!FIRST) {
           if (k1 > 1 || from_state) {
             const float* hb = hin + (P ^ 1) * 4 * BW;
@@ -493,6 +522,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
             }
           }
         }
+#endif
         pairs_load<NP>(xk[P], ring_row(a1), lane);      // read two ticks ago as row a1 = this tick's a2: consumed above
         const float cdown = ((unsigned)(a1 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
         if constexpr (FIRST) pipe_stage_first<NP>(xk[P], sol1, cdown, cstep, cr_last, beta1, o1[P]);

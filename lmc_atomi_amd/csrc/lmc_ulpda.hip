@@ -395,6 +395,178 @@ hipError_t ulpda_finish_philox(float* x, float* xhat, const float* u, int64_t C,
   return hipGetLastError();
 }
 
+// ---- fused finish + dual update (gfirst = false, algs.py:446-448):  x <- u + s xi ; xhat = x + theta (x - x_old) ;
+//      y <- prox_{mu g*}(y + mu A xhat)   in ONE row-streaming pass.  xhat is consumed in registers and never stored: with gfirst = false
+// nothing else reads it.  One wavefront owns the full width of a band of rows of one chain (lane = PXL consecutive pixels, W <= 64 PXL,
+// W % 4 == 0), so the right-hand neighbour of the forward difference is in the same lane or one wave-shift DPP move away, and the row
+// below is the next row the wave computes -- a band looks one row ahead (recomputed by the next band: its Philox quad included).
+// HBM bytes per pixel: x_old 4 + u 4 + y 8 read, x 4 + y 8 written = 28 (the two separate passes: 16 + 20 = 36).  x_new goes to a second
+// state buffer (ping-pong).
+template <int PXL>
+__global__ __launch_bounds__(256) void ulpda_finish_dual_kernel(const float* __restrict__ x, float* __restrict__ xnew, const float* __restrict__ u, float* __restrict__ y,
+                                                                const float* __restrict__ xi, int H, int W, int C, int band_rows, int nbands,
+                                                                float s, float theta, float mu, float radius, int iso, int philox,
+                                                                uint32_t key0, uint32_t key1, uint32_t iteration, uint32_t chain_offset) {
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gw >= C * nbands) return;
+  const int chain = gw / nbands, band = gw - chain * nbands;
+  const int r0 = band * band_rows, r1 = min(r0 + band_rows, H);      // band_rows % 4 == 0: bands start on Philox quad rows
+  const int c0 = lane * PXL;
+  const size_t img = (size_t)H * W;
+  const float* __restrict__ xc = x + (size_t)chain * img;       // x_old: read-only here (the look-ahead row of a band is the first row
+  float* __restrict__ xo_ = xnew + (size_t)chain * img;         // of the next one, which writes its x_new concurrently: separate buffers)
+  const float* __restrict__ uc = u + (size_t)chain * img;
+  const float* __restrict__ nc = xi ? xi + (size_t)chain * img : nullptr;
+  float* __restrict__ yr = y + (size_t)chain * 2 * img;
+  float* __restrict__ yc = yr + img;
+  constexpr int NG = PXL / 4;
+  bool gok[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) gok[g] = c0 + 4 * g < W;
+  float nz[PXL][4];                    // normals of the current quad row-group: [pixel][row in quad]
+  float xh_prev[PXL], xh_cur[PXL];
+#pragma unroll
+  for (int k = 0; k < PXL; ++k) { xh_prev[k] = 0.f; xh_cur[k] = 0.f; nz[k][0] = nz[k][1] = nz[k][2] = nz[k][3] = 0.f; }
+  const int i_end = r1 < H ? r1 : H - 1;              // last row whose xhat is formed: the look-ahead row r1, or the last image row
+  // software pipeline: the loads of row i + 1 (x_old, u, injected noise, and the dual rows of row i) are issued before the arithmetic of
+  // row i; vector-memory operations complete in order, so they stay in flight behind nothing but the stores of row i - 1
+  float4 xo4[2][NG], uu4[2][NG], nn4[2][NG], ya4[2][NG], yb4[2][NG];
+  auto fetch = [&](const int slot, const int row) __attribute__((always_inline)) {
+    const size_t go = (size_t)min(row, H - 1) * W;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int cc = gok[g] ? c0 + 4 * g : 0;             // lanes past the row read its start (valid memory), their results are never stored
+      xo4[slot][g] = *reinterpret_cast<const float4*>(xc + go + cc);
+      uu4[slot][g] = *reinterpret_cast<const float4*>(uc + go + cc);
+      if (nc) nn4[slot][g] = *reinterpret_cast<const float4*>(nc + go + cc);
+      if (row > r0) {                                      // dual rows of row - 1
+        ya4[slot][g] = *reinterpret_cast<const float4*>(yr + go - W + cc);
+        yb4[slot][g] = *reinterpret_cast<const float4*>(yc + go - W + cc);
+      }
+    }
+  };
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) nn4[sl][g] = ya4[sl][g] = yb4[sl][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+  fetch(0, r0);
+  auto row_step = [&](auto ss, const int i) __attribute__((always_inline)) {
+    constexpr int SL = decltype(ss)::value;
+    if (i < i_end) fetch(SL ^ 1, i + 1);
+    if (philox && (i & 3) == 0) {
+#pragma unroll
+      for (int k = 0; k < PXL; ++k)
+        if (gok[k >> 2]) quad_normals(key0, key1, iteration, chain_offset + (uint32_t)chain, (uint32_t)(i >> 2) * (uint32_t)W + (uint32_t)(c0 + k), nz[k]);
+    }
+    const size_t go = (size_t)i * W;
+    // x_new and xhat of row i
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float xo[4] = {xo4[SL][g].x, xo4[SL][g].y, xo4[SL][g].z, xo4[SL][g].w};
+      const float uu[4] = {uu4[SL][g].x, uu4[SL][g].y, uu4[SL][g].z, uu4[SL][g].w};
+      const float nn[4] = {nn4[SL][g].x, nn4[SL][g].y, nn4[SL][g].z, nn4[SL][g].w};
+      float xn[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float nv = philox ? nz[4 * g + q][i & 3] : nn[q];
+        xn[q] = (philox || nc) ? fmaf(s, nv, uu[q]) : uu[q];
+        xh_cur[4 * g + q] = fmaf(theta, xn[q] - xo[q], xn[q]);
+      }
+      if (gok[g] && i < r1) *reinterpret_cast<float4*>(xo_ + go + c0 + 4 * g) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+    }
+    // dual update of row j = i - 1 (its vertical difference needs row i)
+    if (i > r0) {
+      const float right_edge = dpp_right0(xh_prev[0]);          // first pixel of the lane to the right (0 past the wave)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const float av[4] = {ya4[SL][g].x, ya4[SL][g].y, ya4[SL][g].z, ya4[SL][g].w}, bv[4] = {yb4[SL][g].x, yb4[SL][g].y, yb4[SL][g].z, yb4[SL][g].w};
+        float ao[4], bo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = 4 * g + q;
+          const float here = xh_prev[k];
+          const float rgt = k == PXL - 1 ? right_edge : xh_prev[k + 1];
+          const float dx = xh_cur[k] - here;
+          const float dy = (c0 + k + 1 < W) ? rgt - here : 0.f;
+          float a = fmaf(mu, dx, av[q]), b = fmaf(mu, dy, bv[q]);
+          if (iso) {
+            const float sc = 1.f / fmaxf(1.f, sqrtf(fmaf(a, a, b * b)) / radius);
+            a *= sc; b *= sc;
+          } else {
+            a = fminf(fmaxf(a, -radius), radius);
+            b = fminf(fmaxf(b, -radius), radius);
+          }
+          ao[q] = a; bo[q] = b;
+        }
+        if (gok[g]) {
+          *reinterpret_cast<float4*>(yr + go - W + c0 + 4 * g) = make_float4(ao[0], ao[1], ao[2], ao[3]);
+          *reinterpret_cast<float4*>(yc + go - W + c0 + 4 * g) = make_float4(bo[0], bo[1], bo[2], bo[3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PXL; ++k) xh_prev[k] = xh_cur[k];
+  };
+  for (int i = r0; i <= i_end; i += 2) {
+    row_step(std::integral_constant<int, 0>{}, i);
+    if (i + 1 <= i_end) row_step(std::integral_constant<int, 1>{}, i + 1);
+  }
+  if (r1 == H) {      // last image row (this band owns it): no row below, dx = 0
+    const size_t go = (size_t)(H - 1) * W;
+    const float right_edge = dpp_right0(xh_prev[0]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (!gok[g]) continue;
+      const float4 a4 = *reinterpret_cast<const float4*>(yr + go + c0 + 4 * g);
+      const float4 b4 = *reinterpret_cast<const float4*>(yc + go + c0 + 4 * g);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+      float ao[4], bo[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = 4 * g + q;
+        const float here = xh_prev[k];
+        const float rgt = k == PXL - 1 ? right_edge : xh_prev[k + 1];
+        const float dy = (c0 + k + 1 < W) ? rgt - here : 0.f;
+        float a = av[q], b = fmaf(mu, dy, bv[q]);
+        if (iso) {
+          const float sc = 1.f / fmaxf(1.f, sqrtf(fmaf(a, a, b * b)) / radius);
+          a *= sc; b *= sc;
+        } else {
+          a = fminf(fmaxf(a, -radius), radius);
+          b = fminf(fmaxf(b, -radius), radius);
+        }
+        ao[q] = a; bo[q] = b;
+      }
+      *reinterpret_cast<float4*>(yr + go + c0 + 4 * g) = make_float4(ao[0], ao[1], ao[2], ao[3]);
+      *reinterpret_cast<float4*>(yc + go + c0 + 4 * g) = make_float4(bo[0], bo[1], bo[2], bo[3]);
+    }
+  }
+}
+
+bool ulpda_finish_dual_supported(int H, int W) { return (W & 3) == 0 && W >= 4 && W <= 512 && H >= 1; }
+
+// xi: injected noise [C][H][W] or NULL; philox != 0 draws the field in place (xi must then be NULL)
+hipError_t ulpda_finish_dual(const float* x, float* xnew, const float* u, float* y, const float* xi, int64_t C, int H, int W, float s, float theta, float mu,
+                             float radius, int iso, int philox, uint32_t key0, uint32_t key1, uint32_t iteration, uint32_t chain_offset,
+                             hipStream_t st) {
+  if (!ulpda_finish_dual_supported(H, W) || C > (1 << 24) || x == xnew) return hipErrorInvalidConfiguration;
+  const int want = (int)((4096 + C - 1) / C);                       // bands per chain for ~4 waves per SIMD
+  int band = (H + want - 1) / want;
+  if (band < 16) band = 16;
+  band = (band + 3) & ~3;
+  const int nbands = (H + band - 1) / band;
+  const long long waves = (long long)C * nbands;
+  const int nblk = (int)((waves + 3) / 4);
+  if (W <= 256)
+    hipLaunchKernelGGL(ulpda_finish_dual_kernel<4>, dim3(nblk), dim3(256), 0, st, x, xnew, u, y, xi, H, W, (int)C, band, nbands, s, theta, mu, radius,
+                       iso, philox, key0, key1, iteration, chain_offset);
+  else
+    hipLaunchKernelGGL(ulpda_finish_dual_kernel<8>, dim3(nblk), dim3(256), 0, st, x, xnew, u, y, xi, H, W, (int)C, band, nbands, s, theta, mu, radius,
+                       iso, philox, key0, key1, iteration, chain_offset);
+  return hipGetLastError();
+}
+
 static inline bool vec4_ok(int H, int W) { return (W & 3) == 0 && (size_t)H * W < (1ull << 31); }
 
 hipError_t ulpda_dual_update(const float* xhat, float* y, int64_t C, int H, int W, float mu, float radius, int iso,
