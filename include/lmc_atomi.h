@@ -108,9 +108,12 @@ typedef struct lmc_problem {
    * 0 (default): after tv_niter dual updates; 1: after tv_niter - 1 ("lagged": one pipeline stage fewer).  Applies to the
    * LMC_PRIOR_TV_ISO prox and to the inner prox of the ME-TV term. */
   int32_t tv_lagged_output;
-  /* pyproximal.TV's per-image early exit on the relative change of the primal objective (its default rtol = 1e-4).  A batched launch
-   * runs the same number of dual iterations for every chain: only 0 (off) is accepted, anything else is LMC_E_UNSUPPORTED -- the
-   * Python drop-in warns and passes 0 (parity holds at rtol = 0; measured divergence in DESIGN section 4). */
+  /* pyproximal.TV's per-image early exit on the relative change of the primal objective (its default rtol = 1e-4, which the reference's
+   * call at prox_lmc_deconv.py:122 does not override).  0 (default): off -- every image runs tv_niter dual iterations in one fused launch
+   * (the fast path; statistically equivalent).  > 0: the exact pass-by-pass path for the LMC_PRIOR_TV_ISO prox of MYULA
+   * samplers and lmc_fused_eval: one launch per loop pass for the iterate, one for its objective, images leave individually; the host reads
+   * the number of images still iterating after every pass, so this path SYNCHRONISES the stream (and costs several times the fast path).
+   * Not with tv_warm, MYMALA, or the inner prox of the ME-TV term (which keeps its fixed count). */
   float tv_rtol;
   /* Step-kernel variant for launches configured from this problem: 0 = the library default (lmc_set_step_variant, itself "auto"
    * unless changed), 1..7 as listed at lmc_set_step_variant. */

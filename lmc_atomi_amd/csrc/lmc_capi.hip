@@ -73,6 +73,7 @@ struct Problem {
   float ncvx_lambda = 0.f, ncvx_gamma = 1.f;
   int ncvx_niter = 0;
   int tv_warm = 0;
+  float tv_rtol = 0.f;      // > 0: pyproximal.TV's per-image early exit (exact pass-by-pass path, tv_prox_rtol)
   int variant = 0;          // 0: the library default (g_variant)
   float implicit_tol = 0.f; // 0: the library default (g_cg_tol); < 0: disabled
 };
@@ -82,7 +83,17 @@ struct Problem {
 struct Scratch {
   float* state[2] = {nullptr, nullptr};   // TV dual state ping-pong, [n][4][H][W] each
   float* extra = nullptr;                 // ME-TV inner prox, [n][H][W]
-  float* prox = nullptr;                  // Haar-l1 prox, [n][H][W]
+  float* prox = nullptr;                  // Haar-l1 prox / early-exit TV prox, [n][H][W]
+  float* rtmp = nullptr;                  // early-exit TV prox: the iterate of the current pass, [n][H][W]
+  size_t n_rtmp = 0;
+  hipError_t need_rtmp(size_t n) {
+    if (n <= n_rtmp) return hipSuccess;
+    if (rtmp) (void)hipFree(rtmp);
+    rtmp = nullptr; n_rtmp = 0;
+    hipError_t e = hipMalloc(&rtmp, sizeof(float) * n);
+    if (e == hipSuccess) n_rtmp = n;
+    return e;
+  }
   double* dbl = nullptr;                  // 2*n doubles
   size_t n_state = 0, n_extra = 0, n_dbl = 0, n_prox = 0;
   hipError_t need_prox(size_t n) {
@@ -182,9 +193,8 @@ int load_problem(const lmc_problem* p, Problem& q) {
     case LMC_PRIOR_TV_ISO:
       if (p->tv_niter < 1 || p->tv_niter > lmc::kMaxTvIters)
         return fail(LMC_E_UNSUPPORTED, "tv_niter %d outside 1..%d", p->tv_niter, lmc::kMaxTvIters);
-      if (p->tv_rtol != 0.f)
-        return fail(LMC_E_UNSUPPORTED, "tv_rtol = %g: the per-image early exit of pyproximal.TV is not built (a batched launch runs the same "
-                    "dual iterations for every chain); pass 0", (double)p->tv_rtol);
+      if (!(p->tv_rtol >= 0.f) || p->tv_rtol >= 1.f) return fail(LMC_E_INVALID, "tv_rtol must be in [0, 1)");
+      q.tv_rtol = p->tv_rtol;
       q.tv_niter = p->tv_niter - (p->tv_lagged_output ? 1 : 0);     // lagged: the iterate after tv_niter - 1 dual updates (0: prox = x)
       q.tv_step = p->tv_step > 0.f ? p->tv_step : 0.125f;
       if (p->tv_betas_host) std::memcpy(q.betas, p->tv_betas_host, sizeof(float) * p->tv_niter);
@@ -488,6 +498,56 @@ int me_tv_prox(const Problem& q, const float* x, float* extra, int64_t n_img, fl
   return LMC_OK;
 }
 
+
+// prox_{pt g}(x), g = sigma TV, with upstream's per-image early exit (lmc_problem.tv_rtol > 0; pyproximal.TV.prox as restated by the
+// CPU checker's tv_prox_fgp): at the top of pass j the iterate sol_j = x - gam div(r_j) (j dual updates) and its primal objective
+// are formed; an image leaves with sol_j as soon as the relative change of the objective drops below rtol (never in pass 0); after
+// tv_niter updates the iterate is returned untested.  Exact, pass by pass, for the whole batch: pass j's iterate is ONE fused launch
+// with j dual iterations from the zero dual (the stages of a longer launch compute the same values), the objective a second one; images
+// that have left keep their iterate (flag / select).  The host reads the number of images still iterating after every pass -- this
+// path synchronises the stream, the fixed-count path (tv_rtol = 0) never does.  Typical MYULA iterates leave after 2-4 passes.
+// sol, tmp: [n][H][W]; obj: 2n doubles (previous, current); flag: n + 1 ints (pass an image left in, -1 = iterating; then the counter).
+int tv_prox_rtol(const Problem& q, float pt, const float* x, float* sol, float* tmp, double* obj, int* flag, int64_t n, float* st0, float* st1,
+                 hipStream_t st) {
+  const float gam = pt * q.prior_sigma;
+  if (!(gam > 0.f)) return fail(LMC_E_INVALID, "TV prox parameter must be > 0 (got %g)", (double)gam);
+  const size_t img = (size_t)q.H * q.W;
+  double *prev = obj, *cur = obj + n;
+  int* n_active = flag + n;
+  HIP_TRY(hipMemsetAsync(obj, 0, sizeof(double) * 2 * n, st));
+  HIP_TRY(hipMemsetAsync(flag, 0xFF, sizeof(int) * n, st));                  // -1: every image iterating
+  const int K = q.tv_niter;
+  for (int j = 0; j <= K; ++j) {
+    const float* it = x;                                                     // pass 0: sol_0 = x
+    if (j > 0) {
+      Problem qj = q;
+      qj.tv_niter = j;
+      qj.ncvx_kind = LMC_NCVX_NONE;
+      lmc::StepArgs A;
+      int rc = make_step_args(qj, 0.f, 0.f, 1.f, pt, 0.f, A);
+      if (rc) return rc;
+      A.C = (int)n; A.x_in = x; A.x_out = tmp;
+      sanitize_pointers(A);
+      hipError_t e = launch_step(A, 0 /* auto: the passes have 1, 2, 3 ... dual iterations, no single variant covers them all */, st, nullptr, st0, st1);
+      if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no step-kernel variant covers a TV prox with %d dual iterations", j);
+      HIP_TRY(e);
+      it = tmp;
+    }
+    if (j == K) {                                                            // out of passes: the rest take sol_K untested
+      HIP_TRY(lmc::launch_tv_rtol_select(it, sol, flag, -1, n, img, st));
+      break;
+    }
+    HIP_TRY(lmc::launch_tv_objective(x, it, n, q.H, q.W, gam, flag, cur, st));
+    HIP_TRY(hipMemsetAsync(n_active, 0, sizeof(int), st));
+    HIP_TRY(lmc::launch_tv_rtol_decide(n, prev, cur, flag, j, (double)q.tv_rtol, n_active, st));
+    if (j > 0) HIP_TRY(lmc::launch_tv_rtol_select(it, sol, flag, j, n, img, st));
+    int active = 0;
+    HIP_TRY(hipMemcpyAsync(&active, n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (active == 0) break;
+  }
+  return LMC_OK;
+}
 }  // namespace
 
 struct lmc_sampler {
@@ -504,7 +564,8 @@ struct lmc_sampler {
   float* tvwarm[2] = {nullptr, nullptr};    // warm-started TV prox: projected dual (p, q) of the previous / this MYULA iteration, [C][2][H][W]
   int wcur = 0;
   float* extra = nullptr;                   // ME-TV inner prox
-  float* pxbuf = nullptr;                   // Haar-l1 prox of the current state
+  float* pxbuf = nullptr;                   // Haar-l1 prox / early-exit TV prox of the current state
+  float* rtmp = nullptr; double* robj = nullptr; int* rflag = nullptr;   // early-exit TV prox (tv_rtol > 0): pass iterate, objectives, flags
   Problem prob;
   int C = 0;
   int64_t chain_offset = 0;
@@ -645,6 +706,16 @@ int lmc_fused_eval(const lmc_problem* prob, const float* x_dev, float* out_dev, 
     A.extra_coef = -q.ncvx_lambda / q.ncvx_gamma;
   }
   if (A.prior_kind == LMC_PRIOR_HAAR_L1) HIP_TRY(g_scratch.need_prox(npx));
+  if (A.prior_kind == LMC_PRIOR_TV_ISO && q.tv_rtol > 0.f) {     // the early-exit prox first, then the fused update with it as a ready-made prox
+    Scratch& sc = g_scratch;
+    HIP_TRY(sc.need_prox(npx));
+    HIP_TRY(sc.need_rtmp(npx));
+    HIP_TRY(sc.need_dbl(3 * (size_t)n_img + 2));
+    rc = tv_prox_rtol(q, pt, x_dev, sc.prox, sc.rtmp, sc.dbl, reinterpret_cast<int*>(sc.dbl + 2 * n_img), n_img, sc.state[0], sc.state[1], S(stream));
+    if (rc) return rc;
+    A.prior_kind = LMC_PRIOR_NONE;
+    A.prox_ext = sc.prox;
+  }
   hipError_t e = launch_step(A, variant_of(q), S(stream), nullptr, g_scratch.state[0], g_scratch.state[1], g_scratch.prox);
   if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no step-kernel variant covers this configuration");
   HIP_TRY(e);
@@ -819,6 +890,13 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
   }
   if (e == hipSuccess && s->prob.ncvx_kind == LMC_NCVX_ME_TV) e = hipMalloc(&s->extra, nbytes);
   if (e == hipSuccess && s->prob.prior_kind == LMC_PRIOR_HAAR_L1) e = hipMalloc(&s->pxbuf, nbytes);
+  if (e == hipSuccess && s->prob.tv_rtol > 0.f && s->base.prior_kind == LMC_PRIOR_TV_ISO) {
+    if (s->prob.tv_warm) { lmc_sampler_destroy(s); return fail(LMC_E_UNSUPPORTED, "tv_rtol > 0 and tv_warm exclude each other"); }
+    e = hipMalloc(&s->pxbuf, nbytes);
+    if (e == hipSuccess) e = hipMalloc(&s->rtmp, nbytes);
+    if (e == hipSuccess) e = hipMalloc(&s->robj, sizeof(double) * 2 * (size_t)s->C);
+    if (e == hipSuccess) e = hipMalloc(&s->rflag, sizeof(int) * ((size_t)s->C + 1));
+  }
   if (e == hipSuccess && s->prob.tv_warm) {
     lmc::StepArgs probe = s->base;
     probe.x_in = s->x[0];
@@ -853,8 +931,10 @@ void lmc_sampler_destroy(lmc_sampler* s) {
   if (!s) return;
   DeviceGuard dg(s->device);
   for (float* b : {s->zero_y, s->xhat, s->ydual, s->uw, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra, s->pxbuf,
-                   s->mx, s->xp, s->mxp, s->tvwarm[0], s->tvwarm[1]})
+                   s->mx, s->xp, s->mxp, s->tvwarm[0], s->tvwarm[1], s->rtmp})
     if (b) (void)hipFree(b);
+  if (s->robj) (void)hipFree(s->robj);
+  if (s->rflag) (void)hipFree(s->rflag);
   if (s->mala_d) (void)hipFree(s->mala_d);
   if (s->flag) (void)hipFree(s->flag);
   if (s->nacc) (void)hipFree(s->nacc);
@@ -1067,7 +1147,7 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
   }
   // graph replay: whole blocks of kGraphIters iterations whose every iteration is kept by the moment accumulators (or none is)
   const bool graph_ok = !s->timing && (!overlap || (getenv("LMC_GRAPH") && atoi(getenv("LMC_GRAPH")) == 1)) && !noise_dev && s->noise_mode != LMC_NOISE_INJECTED && s->prob.ncvx_kind != LMC_NCVX_ME_TV &&
-                        !s->tvwarm[0] && (!s->moments || s->thin == 1) && graph_wanted(s);
+                        !s->tvwarm[0] && !s->rtmp && (!s->moments || s->thin == 1) && graph_wanted(s);
   bool graph_enabled = false;
   for (int k = 0; k < n_iters; ++k) {
     if (graph_ok && s->plain_done && n_iters - k >= kGraphIters && (!s->moments || s->iteration >= s->burn_in) &&
@@ -1107,6 +1187,12 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * k], st));
     const char* kname = nullptr;
     hipError_t e;
+    if (s->rtmp && A.prior_kind == LMC_PRIOR_TV_ISO) {   // early-exit TV prox first (exact pass-by-pass path), consumed as a ready-made prox
+      int rc = tv_prox_rtol(s->prob, s->epsg * s->gamma, A.x_in, s->pxbuf, s->rtmp, s->robj, s->rflag, s->C, s->tvstate[0], s->tvstate[1], st);
+      if (rc) return rc;
+      A.prior_kind = LMC_PRIOR_NONE;
+      A.prox_ext = s->pxbuf;
+    }
     if (s->tvwarm[0]) {     // warm-started TV prox: the dual of the previous iteration in, this iteration's out
       A.tv_in = s->tvwarm[s->wcur];
       A.tv_out = s->tvwarm[s->wcur ^ 1];
@@ -1152,6 +1238,7 @@ int lmc_mymala_create(const lmc_myula_config* cfg, lmc_sampler** out) {
   lmc_sampler* s = *out;
   *out = nullptr;
   if (s->tvwarm[0]) { lmc_sampler_destroy(s); return fail(LMC_E_UNSUPPORTED, "MYMALA needs a proposal mean that is a function of x alone: tv_warm is not allowed"); }
+  if (s->rtmp) { lmc_sampler_destroy(s); return fail(LMC_E_UNSUPPORTED, "MYMALA with tv_rtol > 0 is not built (use the fixed-count prox, tv_rtol = 0)"); }
   s->kind = 2;
   const size_t nbytes = sizeof(float) * (size_t)s->C * s->prob.H * s->prob.W;
   hipError_t e = hipMalloc(&s->mx, nbytes);

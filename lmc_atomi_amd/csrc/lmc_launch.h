@@ -37,6 +37,10 @@ hipError_t launch_moments_bg(const float* x, int C, int H, int W, double* s1, do
 hipError_t launch_energies(const float* x, int64_t n_img, const EnergyArgs& E, double* f_out, double* g_out,
                            hipStream_t st);
 hipError_t launch_bump_u32(uint32_t* p, uint32_t by, hipStream_t st);
+// pieces of the exact early-exit path of the TV prox (lmc_problem.tv_rtol > 0)
+hipError_t launch_tv_objective(const float* x, const float* sol, int64_t n, int H, int W, float gam, const int* flag, double* obj, hipStream_t st);
+hipError_t launch_tv_rtol_decide(int64_t n, double* prev, double* cur, int* flag, int pass, double rtol, int* n_active, hipStream_t st);
+hipError_t launch_tv_rtol_select(const float* tmp, float* sol, const int* flag, int pass, int64_t n, size_t img, hipStream_t st);
 int hbm_copy_probe_shapes();
 hipError_t launch_hbm_copy_probe(const float* x, float* y, size_t n_floats, int shape, hipStream_t st);
 hipError_t launch_noise(float* out, int C, int H, int W, uint32_t key0, uint32_t key1, uint32_t iteration,

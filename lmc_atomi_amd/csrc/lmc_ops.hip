@@ -701,6 +701,80 @@ hipError_t launch_hbm_copy_probe(const float* x, float* y, size_t n_floats, int 
   return hipGetLastError();
 }
 
+// ---- pyproximal.TV's early exit (lmc_problem.tv_rtol > 0): the pieces of the exact, pass-by-pass path (lmc_capi.hip: tv_prox_rtol) -------
+// obj[c] += 1/2 ||x_c - sol_c||^2 + gam * TV_iso(sol_c) for the chains still iterating (flag[c] < 0): the primal objective upstream
+// evaluates at the top of every loop pass.  fp32 terms, fp64 sums.
+__global__ __launch_bounds__(256) void tv_objective_kernel(const float* __restrict__ x, const float* __restrict__ sol, int H, int W, float gam,
+                                                           const int* __restrict__ flag, double* __restrict__ obj) {
+  __shared__ double scratch[4];
+  const size_t c = blockIdx.x;
+  if (flag[c] >= 0) return;                    // uniform over the block
+  const size_t img = (size_t)H * W;
+  const float* xc = x + c * img;
+  const float* sc = sol + c * img;
+  double acc = 0.0;
+  for (size_t p = (size_t)blockIdx.y * blockDim.x + threadIdx.x; p < img; p += (size_t)gridDim.y * blockDim.x) {
+    const int r = (int)(p / W), col = (int)(p - (size_t)r * W);
+    const float v = sc[p];
+    const float d = xc[p] - v;
+    const float dx = (r + 1 < H) ? sc[p + W] - v : 0.f;
+    const float dy = (col + 1 < W) ? sc[p + 1] - v : 0.f;
+    acc += 0.5 * (double)d * (double)d + (double)gam * (double)sqrtf(fmaf(dx, dx, dy * dy));
+  }
+  const double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) unsafeAtomicAdd(&obj[c], t);
+}
+
+// One thread per chain, pass j >= 1: a chain still iterating leaves when |obj_j - obj_{j-1}| / obj_j < rtol (the CPU checker's rule, tv_prox_fgp --
+// upstream's loop); flag[c] = j marks it.  Otherwise obj_j becomes its obj_{j-1}.  n_active counts the rest.
+__global__ void tv_rtol_decide_kernel(int64_t n, double* __restrict__ prev, double* __restrict__ cur, int* __restrict__ flag, int pass, double rtol,
+                                      int* __restrict__ n_active) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n || flag[c] >= 0) return;
+  const double o = cur[c], p = prev[c];
+  const double rel = o > 0.0 ? fabs(o - p) / o : 2.0 * rtol;
+  if (pass >= 1 && rel < rtol) { flag[c] = pass; }
+  else { prev[c] = o; atomicAdd(n_active, 1); }
+  cur[c] = 0.0;
+}
+
+// sol_c <- tmp_c for the chains whose flag equals `pass` (the pass they left in; -1: the ones that ran out of passes)
+__global__ __launch_bounds__(256) void tv_rtol_select_kernel(const float4* __restrict__ tmp, float4* __restrict__ sol, const int* __restrict__ flag,
+                                                             int pass, size_t img4) {
+  const size_t c = blockIdx.x;
+  if (flag[c] != pass) return;
+  for (size_t k = (size_t)blockIdx.y * blockDim.x + threadIdx.x; k < img4; k += (size_t)gridDim.y * blockDim.x) sol[c * img4 + k] = tmp[c * img4 + k];
+}
+__global__ __launch_bounds__(256) void tv_rtol_select1_kernel(const float* __restrict__ tmp, float* __restrict__ sol, const int* __restrict__ flag,
+                                                              int pass, size_t img) {
+  const size_t c = blockIdx.x;
+  if (flag[c] != pass) return;
+  for (size_t k = (size_t)blockIdx.y * blockDim.x + threadIdx.x; k < img; k += (size_t)gridDim.y * blockDim.x) sol[c * img + k] = tmp[c * img + k];
+}
+
+hipError_t launch_tv_objective(const float* x, const float* sol, int64_t n, int H, int W, float gam, const int* flag, double* obj, hipStream_t st) {
+  const size_t img = (size_t)H * W;
+  int gy = (int)((img + 255) / 256);
+  if (gy > 64) gy = 64;
+  hipLaunchKernelGGL(tv_objective_kernel, dim3((unsigned)n, gy), dim3(256), 0, st, x, sol, H, W, gam, flag, obj);
+  return hipGetLastError();
+}
+hipError_t launch_tv_rtol_decide(int64_t n, double* prev, double* cur, int* flag, int pass, double rtol, int* n_active, hipStream_t st) {
+  hipLaunchKernelGGL(tv_rtol_decide_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, n, prev, cur, flag, pass, rtol, n_active);
+  return hipGetLastError();
+}
+hipError_t launch_tv_rtol_select(const float* tmp, float* sol, const int* flag, int pass, int64_t n, size_t img, hipStream_t st) {
+  int gy = (int)((img / 4 + 255) / 256);
+  if (gy > 64) gy = 64;
+  if (gy < 1) gy = 1;
+  if ((img & 3) == 0)
+    hipLaunchKernelGGL(tv_rtol_select_kernel, dim3((unsigned)n, gy), dim3(256), 0, st, reinterpret_cast<const float4*>(tmp), reinterpret_cast<float4*>(sol),
+                       flag, pass, img / 4);
+  else
+    hipLaunchKernelGGL(tv_rtol_select1_kernel, dim3((unsigned)n, gy), dim3(256), 0, st, tmp, sol, flag, pass, img);
+  return hipGetLastError();
+}
+
 // *p += by (one thread): the device-side iteration base of a replayed hipGraph of MYULA iterations
 __global__ void bump_u32_kernel(uint32_t* p, uint32_t by) { *p += by; }
 hipError_t launch_bump_u32(uint32_t* p, uint32_t by, hipStream_t st) {

@@ -20,6 +20,9 @@ namespace lmc {
 #ifndef LMC_WARM_MIN_WAVES
 #define LMC_WARM_MIN_WAVES 1
 #endif
+#ifndef LMC_PIPE_SCHED
+#define LMC_PIPE_SCHED 0     // 1: T waves request stage k1's inputs first and hand stage k2's output over while computing it (see pipe_stage_emit)
+#endif
 #ifdef LMC_EXP_NOBARRIER   // timing experiment: waves free-run (results are wrong)
 #define PIPE_TICK_SYNC() do {} while (0)
 #else
@@ -120,6 +123,53 @@ __device__ __forceinline__ void pipe_stage(const v2f (&xa)[NP], const v2f (&r1)[
     out.ss[i] = pk_fma(vb, qn - in0.q[i], qn);
     out.p[i] = pn;
     out.q[i] = qn;
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) solb[i] = sol[i];
+}
+
+// The same stage with its output handed to the next wave as it is produced: after each group of two pixel pairs the four float4
+// of the group (rr, ss, p, q) are stored to the hand-off slot `hb`, and a scheduling barrier keeps the next group's arithmetic behind
+// them.  All T waves of a workgroup run in lockstep; issued in one block after the arithmetic (pipe_stage + pairs_store) their stores
+// and the reads that follow arrive at the LDS together -- 40 ds_write_b128 (13 cycles each) and 50 ds_read_b128 per tick, ~700 cycles
+// during which every wave waits -- while spread over the arithmetic they hide behind it.
+template <int NP>
+__device__ __forceinline__ void pipe_stage_emit(const v2f (&xa)[NP], const v2f (&r1)[NP], const v2f (&s1)[NP], const DualRow<NP>& in0,
+                                                v2f (&solb)[NP], float gam, float cdown, float cstep, float cr_last, float beta,
+                                                float* hb, int BWf, int lane) {
+  v2f sol[NP];
+  const float ssl0 = dpp_left0(s1[NP - 1].y);
+  const v2f ngam = pk_set(-gam), ncd = pk_set(-cdown), vb = pk_set(beta);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const v2f ssl = v2f{i == 0 ? ssl0 : s1[i - 1].y, s1[i].x};
+    sol[i] = pk_fma(ngam, (r1[i] - in0.rr[i]) + (s1[i] - ssl), xa[i]);
+  }
+  const float solr_last = dpp_right0(solb[0].x);
+#pragma unroll
+  for (int g = 0; g < NP / 2; ++g) {
+    v2f orr[2], oss[2], op[2], oq[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = 2 * g + h;
+      const v2f solr = v2f{solb[i].y, i == NP - 1 ? solr_last : solb[i + 1].x};
+      const v2f ncr = i == NP - 1 ? v2f{-cstep, -cr_last} : pk_set(-cstep);
+      const v2f r = pk_fma(ncd, sol[i] - solb[i], in0.rr[i]);
+      const v2f s = pk_fma(ncr, solr - solb[i], in0.ss[i]);
+      const v2f n2 = pk_fma(r, r, s * s);
+      const v2f inv = v2f{__builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(n2.x), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(n2.y), 0.f, 1.f)};
+      const v2f pn = r * inv, qn = s * inv;
+      orr[h] = pk_fma(vb, pn - in0.p[i], pn);
+      oss[h] = pk_fma(vb, qn - in0.q[i], qn);
+      op[h] = pn;
+      oq[h] = qn;
+    }
+    float* d = hb + g * 256 + lane * 4;
+    *reinterpret_cast<float4*>(d) = make_float4(orr[0].x, orr[0].y, orr[1].x, orr[1].y);
+    *reinterpret_cast<float4*>(d + BWf) = make_float4(oss[0].x, oss[0].y, oss[1].x, oss[1].y);
+    *reinterpret_cast<float4*>(d + 2 * BWf) = make_float4(op[0].x, op[0].y, op[1].x, op[1].y);
+    *reinterpret_cast<float4*>(d + 3 * BWf) = make_float4(oq[0].x, oq[0].y, oq[1].x, oq[1].y);
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int i = 0; i < NP; ++i) solb[i] = sol[i];
@@ -482,6 +532,38 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
       constexpr int P = decltype(uu)::value & 1;
       const int a2 = t - E - 2 * k2, a1 = t - E - 2 * k1;
+#if LMC_PIPE_SCHED
+      if constexpr (!CHAIN && !SINGLE && NP >= 2) {
+        // (1) everything stage k1 will read is requested first: the previous wave's hand-off rows (written last tick) and the x row
+        //     (into a spare register row: stage k2 below still reads the old xk[P]); (2) stage k2, whose inputs are registers, runs
+        //     while those reads land, and hands its output over group by group; (3) stage k1 finds its inputs in registers.
+        v2f xkn[NP];
+        if constexpr (!FIRST) {
+          if (k1 > 1) {
+            const float* hb = hin + (P ^ 1) * 4 * BW;
+            pairs_load<NP>(inb[P].rr, hb, lane);
+            pairs_load<NP>(inb[P].ss, hb + BW, lane);
+            pairs_load<NP>(inb[P].p, hb + 2 * BW, lane);
+            pairs_load<NP>(inb[P].q, hb + 3 * BW, lane);
+          }
+        }
+        pairs_load<NP>(xkn, ring_row(a1), lane);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const float cdown = ((unsigned)(a2 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
+          pipe_stage_emit<NP>(xk[P], o1[P ^ 1].rr, o1[P ^ 1].ss, o1[P], sol2, gam, cdown, cstep, cr_last, beta2, hout + P * 4 * BW, BW, lane);
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) xk[P][k] = xkn[k];
+        {
+          const float cdown = ((unsigned)(a1 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
+          if constexpr (FIRST) pipe_stage_first<NP>(xk[P], sol1, cdown, cstep, cr_last, beta1, o1[P]);
+          else pipe_stage<NP>(xk[P], inb[P].rr, inb[P].ss, inb[P ^ 1], sol1, gam, cdown, cstep, cr_last, beta1, o1[P]);
+        }
+        PIPE_TICK_SYNC();
+        return;
+      }
+#endif
 #ifdef LMC_EXP_EARLY_HANDOFF
       // the hand-off rows for stage k1 (written by the previous wave last tick) are requested before stage k2's arithmetic, which needs
       // registers only: their LDS latency hides behind it instead of stalling the wave between the two stages

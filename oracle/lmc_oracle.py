@@ -739,6 +739,10 @@ def myula_step(x, y, h, offset, sigma_f, tau, gamma, prior, xi, mask=None):
             px, prior["dual"] = tv_prox_fgp(x, float(t) * prior["sigma"], prior["niter"], step=prior.get("step", 0.125),
                                             betas=prior.get("betas"), momentum=prior.get("momentum", "unlocbox"),
                                             dual0=prior.get("dual"), return_dual=True)
+        elif prior.get("rtol", 0.0) > 0.0:     # upstream's early exit is per image: one call per chain
+            flat = x.reshape((-1,) + x.shape[-2:])
+            px = np.stack([tv_prox_fgp(xc, float(t) * prior["sigma"], prior["niter"], step=prior.get("step", 0.125), betas=prior.get("betas"),
+                                       momentum=prior.get("momentum", "unlocbox"), rtol=prior["rtol"]) for xc in flat]).reshape(x.shape)
         else:
             px = tv_prox_fgp(x, float(t) * prior["sigma"], prior["niter"], step=prior.get("step", 0.125),
                              betas=prior.get("betas"), momentum=prior.get("momentum", "unlocbox"))

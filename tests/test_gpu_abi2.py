@@ -138,17 +138,57 @@ def test_warm_dual_refusals(la):
         la.MYULASampler(pf, la.TV(shape, sigma=0.3, niter=10, warm=True), shape, n_chains=1, tau=TAU, gamma=GAMMA)
     with pytest.raises(la.LMCError, match="tv_warm"):
         la.MYMALASampler(pf, la.TV(shape, sigma=0.3, niter=2, warm=True), shape, n_chains=1, tau=TAU, gamma=GAMMA)
-    # tv_rtol is refused at the ABI, warned about by the drop-in
-    with pytest.warns(RuntimeWarning, match="early exit"):
-        tv = la.TV(shape, sigma=0.3, niter=10, rtol=1e-4)
-    smp = la.MYULASampler(pf, tv, shape, n_chains=1, tau=TAU, gamma=GAMMA)      # runs the fixed count
-    smp.step(1)
-    smp.close()
-    prob = la.proximal._Problem(shape, prior=tv.prior_descriptor())
-    prob.c.tv_rtol = 1e-4
-    x = la._dev.to_dev(np.zeros(shape))
+    # tv_rtol > 0 excludes the warm dual and MYMALA
     with pytest.raises(la.LMCError, match="tv_rtol"):
-        la._capi.check(la._dev.lib().lmc_fused_eval(C.byref(prob.c), la._dev.ptr(x), la._dev.ptr(x.clone()), 1, 0.0, 0.0, 1.0, 1.0, None))
+        la.MYULASampler(pf, la.TV(shape, sigma=0.3, niter=2, warm=True, rtol=1e-4), shape, n_chains=1, tau=TAU, gamma=GAMMA)
+    with pytest.raises(la.LMCError, match="tv_rtol"):
+        la.MYMALASampler(pf, la.TV(shape, sigma=0.3, niter=10, rtol=1e-4), shape, n_chains=1, tau=TAU, gamma=GAMMA)
+
+
+@pytest.mark.parametrize("shape,K", [((24, 136), 10), ((40, 264), 10), ((20, 64), 10), ((24, 136), 4)])
+def test_tv_rtol_early_exit_matches_the_checker(la, shape, K):
+    """pyproximal.TV's per-image early exit (rtol = 1e-4, upstream's default, which the reference's call leaves in force): the exact
+    pass-by-pass device path against the checker's rtol branch, chain by chain, injected noise -- the chains leave their proxes after
+    different numbers of passes (x0 differs per chain: one starts from zero, where the first proxes run to the end)."""
+    img, h, y = synth(shape)
+    rng = np.random.default_rng(11)
+    C_, nit = 4, 8
+    x0 = img[None] + rng.normal(0, 8, (C_,) + shape)
+    x0[0] = 0.0
+    noise = rng.standard_normal((nit, C_) + shape)
+    pf = la.L2(Op=la.Convolve2D(shape, h, offset=(2, 2)), b=y, sigma=1 / SIGMA ** 2)
+    pg = la.TV(shape, sigma=0.3, niter=K, rtol=1e-4)
+    smp = la.MYULASampler(pf, pg, shape, n_chains=C_, tau=TAU, gamma=GAMMA, noise="injected")
+    smp.set_state(x0)
+    smp.step(nit, noise=noise)
+    got = smp.get_state().cpu().numpy()
+    pri = {"kind": "tv", "sigma": 0.3, "niter": K, "t": GAMMA}
+    ref = oracle_steps(x0, y, h, 5, dict(pri, rtol=1e-4), noise)
+    fixed = oracle_steps(x0, y, h, 5, pri, noise)
+    assert rel(got, ref) < 3e-5, rel(got, ref)
+    assert rel(got, fixed) > 3 * rel(got, ref)          # the early exit is visible, and it is the checker's
+    smp.close()
+    # the stateless prox honours it too (lmc_fused_eval)
+    px = pg.prox(x0[1].ravel(), GAMMA).reshape(shape)
+    assert rel(px, O.tv_prox_fgp(x0[1], 0.3 * GAMMA, K, rtol=1e-4)) < 5e-6
+    assert rel(px, O.tv_prox_fgp(x0[1], 0.3 * GAMMA, K)) > 1e-5
+
+
+def test_drop_in_reproduces_the_reference_at_its_configured_rtol(la, golden):
+    """tests/golden/algs_rtol.npz: the reference's OWN MYULA loop run with the TV prox keeping upstream's default rtol = 1e-4 (through the
+    checker's rtol branch).  The drop-in with ``TV(rtol=1e-4)`` and the reference's PCG64 noise reproduces that trajectory; the
+    fixed-count default reproduces the rtol = 0 one -- and the two stored trajectories differ by 1.5e-4."""
+    g = golden("algs_rtol.npz")
+    ny, nx, k, seed = (int(v) for v in g["meta"])
+    sigma, tau_reg, tau, gamma = (float(v) for v in g["params"])
+    shape = (ny, nx)
+    pf = la.L2(Op=la.Convolve2D(shape, g["h"], offset=(k // 2, k // 2)), b=g["y"], sigma=1 / sigma ** 2)
+    for tag, rtol in (("rtol1e-4", 1e-4), ("rtol0", 0.0)):
+        xs = la.MoreauYosidaUnadjustedLangevin(pf, la.TV(shape, sigma=tau_reg, niter=10, rtol=rtol), np.zeros(ny * nx), tau=tau, gamma=gamma,
+                                               niter=41, seed=seed, rng="pcg64")
+        want = g[f"myula_tv_{tag}"][:5]                     # iterates 0, 10, 20, 30, 40
+        assert rel(xs[::10], want) < 5e-5, (tag, rel(xs[::10], want))
+    assert rel(g["myula_tv_rtol1e-4"][:5], g["myula_tv_rtol0"][:5]) > 5e-5
 
 
 def test_allreduce_moments_through_the_c_abi(la):

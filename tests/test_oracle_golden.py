@@ -229,7 +229,7 @@ def test_tv_rtol_golden_set_and_its_divergence_from_the_fixed_count_prox(golden)
     traj = np.linalg.norm(a - b, axis=1) / np.linalg.norm(a, axis=1)
     mean_div = np.linalg.norm(a.mean(0) - b.mean(0)) / np.linalg.norm(a.mean(0))
     me_div = np.linalg.norm(g["ncvx_me_grad_rtol0"] - g["ncvx_me_grad_rtol1e-4"]) / np.linalg.norm(g["ncvx_me_grad_rtol0"])
-    print(f"TV rtol=1e-4 vs rtol=0 under the reference's MYULA loop (32x32, 200 its, same PCG64 noise): trajectory rel-L2 "
+    print(f"TV rtol=1e-4 vs rtol=0 under the reference's MYULA loop (24x136, 200 its, same PCG64 noise): trajectory rel-L2 "
           f"max {traj.max():.2e} (last {traj[-1]:.2e}); mean over stored iterates {mean_div:.2e}; ME-TV gradient {me_div:.2e}")
     assert traj.max() < 1e-3 and mean_div < 5e-4       # measured 1.5e-4 / 8e-5: below the 1e-3 north-star tolerance, and on record
     assert me_div < 5e-2
