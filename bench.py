@@ -121,6 +121,12 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=20)
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line and nothing else: libraries that print banners on fd 1 (RCCL's version block at communicator set-up)
+    # are sent to stderr for the whole run; the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -319,7 +325,8 @@ def main():
             out["config"]["tau_scale"] = args.tau_scale
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W, h, y, sigma, tau_reg, args.tv_iters, args.cpu_chains, args.cpu_iters)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     smp.close()
     if use_dist:
         dist.destroy_process_group()
