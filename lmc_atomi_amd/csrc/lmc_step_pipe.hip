@@ -3,8 +3,6 @@
 // read / write the dual state in HBM (chained launches, warm-started prox) are in lmc_step_pipe_chain.hip.
 #include "lmc_step_pipe_kernel.h"
 
-#include <cstdlib>
-
 namespace lmc {
 
 int centred_blur_taps(const StepArgs& a, float* uc, float* vc);   // lmc_step_rows.hip
@@ -73,11 +71,6 @@ hipError_t launch_step_pipe(StepArgs a, hipStream_t st, float* state0, float* st
   if (links == 0 || (links > 1 && (!state0 || !state1))) return hipErrorInvalidConfiguration;
   const int KT = pipe_taps(a);
   if (links == 1) {
-    // two-team layout for the headline shape: 264..512 columns, K = 10, nothing but the update itself (no energy by-products, no MC-TV /
-    // ME-TV terms, whose seams are not built); LMC_PIPE_TEAMS=0 keeps the one-team kernel (A/B runs)
-    static const bool teams_on = [] { const char* e = getenv("LMC_PIPE_TEAMS"); return e && atoi(e) != 0; }();
-    if (teams_on && a.tv.niter == 10 && a.W > 256 && (a.W & 7) == 0 && !a.f_out && !a.g_out && a.ncvx_kind == LMC_NCVX_NONE && !a.extra)
-      return pipe_dispatch_teams<10>(a, KT, st);
     switch (a.tv.niter) {
       case 2: return pipe_dispatch_k<2, false>(a, KT, st);
       case 6: return pipe_dispatch_k<6, false>(a, KT, st);

@@ -20,9 +20,10 @@ namespace lmc {
 #ifndef LMC_WARM_MIN_WAVES
 #define LMC_WARM_MIN_WAVES 1
 #endif
-#ifndef LMC_PIPE_SCHED
-#define LMC_PIPE_SCHED 0     // 1: T waves request stage k1's inputs first and hand stage k2's output over while computing it (see pipe_stage_emit)
-#endif
+// Timing experiments of round 2 that were measured and removed again (git history): stage k1's hand-off reads before stage
+// k2's arithmetic (1.876 ms), the same with stage k2's stores interleaved with its arithmetic behind scheduling barriers (1.799 ms), and the
+// two-team layout -- 16 waves of 4 pixels per lane, the teams' roles on complementary SIMDs, the column seam through LDS; exact -- at commit
+// 4183175 (1.811 ms).  Base: 1.749 ms.
 #ifdef LMC_EXP_NOBARRIER   // timing experiment: waves free-run (results are wrong)
 #define PIPE_TICK_SYNC() do {} while (0)
 #else
@@ -95,26 +96,19 @@ struct DualRow { v2f rr[NP], ss[NP], p[NP], q[NP]; };
 
 // One FGP dual iteration on NP pixel pairs per lane.  r1, s1 = (rr, ss)^{k-1} on row a; in0 = (rr, ss, p, q)^{k-1} on row
 // b = a-1; solb = sol^k on row b (in) -> sol^k on row a (out); out = (rr, ss, p, q)^k on row b.
-// Seam (two-team layout, TEAMS == 2): the lane at a team's inner edge takes its horizontal neighbour from the other team instead of the
-// wave shift: `seam.useL` replaces the left neighbour of the first pixel (ssl), `seam.useR` the right neighbour of the last one (solr).
-struct PipeSeam { bool useL, useR; float ssl, solr; };
-__device__ __forceinline__ PipeSeam no_seam() { return PipeSeam{false, false, 0.f, 0.f}; }
-
 template <int NP>
 __device__ __forceinline__ void pipe_stage(const v2f (&xa)[NP], const v2f (&r1)[NP], const v2f (&s1)[NP], const DualRow<NP>& in0,
                                            v2f (&solb)[NP], float gam, float cdown, float cstep, float cr_last, float beta,
-                                           DualRow<NP>& out, const PipeSeam seam = PipeSeam{false, false, 0.f, 0.f}) {
+                                           DualRow<NP>& out) {
   v2f sol[NP];
-  float ssl0 = dpp_left0(s1[NP - 1].y);
-  if (seam.useL) ssl0 = seam.ssl;
+  const float ssl0 = dpp_left0(s1[NP - 1].y);
   const v2f ngam = pk_set(-gam), ncd = pk_set(-cdown), vb = pk_set(beta);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const v2f ssl = v2f{i == 0 ? ssl0 : s1[i - 1].y, s1[i].x};
     sol[i] = pk_fma(ngam, (r1[i] - in0.rr[i]) + (s1[i] - ssl), xa[i]);
   }
-  float solr_last = dpp_right0(solb[0].x);
-  if (seam.useR) solr_last = seam.solr;
+  const float solr_last = dpp_right0(solb[0].x);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const v2f solr = v2f{solb[i].y, i == NP - 1 ? solr_last : solb[i + 1].x};
@@ -135,60 +129,12 @@ __device__ __forceinline__ void pipe_stage(const v2f (&xa)[NP], const v2f (&r1)[
   for (int i = 0; i < NP; ++i) solb[i] = sol[i];
 }
 
-// The same stage with its output handed to the next wave as it is produced: after each group of two pixel pairs the four float4
-// of the group (rr, ss, p, q) are stored to the hand-off slot `hb`, and a scheduling barrier keeps the next group's arithmetic behind
-// them.  All T waves of a workgroup run in lockstep; issued in one block after the arithmetic (pipe_stage + pairs_store) their stores
-// and the reads that follow arrive at the LDS together -- 40 ds_write_b128 (13 cycles each) and 50 ds_read_b128 per tick, ~700 cycles
-// during which every wave waits -- while spread over the arithmetic they hide behind it.
-template <int NP>
-__device__ __forceinline__ void pipe_stage_emit(const v2f (&xa)[NP], const v2f (&r1)[NP], const v2f (&s1)[NP], const DualRow<NP>& in0,
-                                                v2f (&solb)[NP], float gam, float cdown, float cstep, float cr_last, float beta,
-                                                float* hb, int BWf, int lane) {
-  v2f sol[NP];
-  const float ssl0 = dpp_left0(s1[NP - 1].y);
-  const v2f ngam = pk_set(-gam), ncd = pk_set(-cdown), vb = pk_set(beta);
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const v2f ssl = v2f{i == 0 ? ssl0 : s1[i - 1].y, s1[i].x};
-    sol[i] = pk_fma(ngam, (r1[i] - in0.rr[i]) + (s1[i] - ssl), xa[i]);
-  }
-  const float solr_last = dpp_right0(solb[0].x);
-#pragma unroll
-  for (int g = 0; g < NP / 2; ++g) {
-    v2f orr[2], oss[2], op[2], oq[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i = 2 * g + h;
-      const v2f solr = v2f{solb[i].y, i == NP - 1 ? solr_last : solb[i + 1].x};
-      const v2f ncr = i == NP - 1 ? v2f{-cstep, -cr_last} : pk_set(-cstep);
-      const v2f r = pk_fma(ncd, sol[i] - solb[i], in0.rr[i]);
-      const v2f s = pk_fma(ncr, solr - solb[i], in0.ss[i]);
-      const v2f n2 = pk_fma(r, r, s * s);
-      const v2f inv = v2f{__builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(n2.x), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(n2.y), 0.f, 1.f)};
-      const v2f pn = r * inv, qn = s * inv;
-      orr[h] = pk_fma(vb, pn - in0.p[i], pn);
-      oss[h] = pk_fma(vb, qn - in0.q[i], qn);
-      op[h] = pn;
-      oq[h] = qn;
-    }
-    float* d = hb + g * 256 + lane * 4;
-    *reinterpret_cast<float4*>(d) = make_float4(orr[0].x, orr[0].y, orr[1].x, orr[1].y);
-    *reinterpret_cast<float4*>(d + BWf) = make_float4(oss[0].x, oss[0].y, oss[1].x, oss[1].y);
-    *reinterpret_cast<float4*>(d + 2 * BWf) = make_float4(op[0].x, op[0].y, op[1].x, op[1].y);
-    *reinterpret_cast<float4*>(d + 3 * BWf) = make_float4(oq[0].x, oq[0].y, oq[1].x, oq[1].y);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int i = 0; i < NP; ++i) solb[i] = sol[i];
-}
-
 // Stage 1 of a launch that starts from the zero dual state: (rr, ss, p, q)^0 = 0, so sol^1 = x and the differences with the previous
 // iterate vanish.  Bit-identical to pipe_stage() fed with zeros (x - 0 = x, fma(c, d, 0) = c*d), at ~60 % of its instructions.
 template <int NP>
 __device__ __forceinline__ void pipe_stage_first(const v2f (&xa)[NP], v2f (&solb)[NP], float cdown, float cstep, float cr_last, float beta,
-                                                 DualRow<NP>& out, const PipeSeam seam = PipeSeam{false, false, 0.f, 0.f}) {
-  float solr_last = dpp_right0(solb[0].x);
-  if (seam.useR) solr_last = seam.solr;
+                                                 DualRow<NP>& out) {
+  const float solr_last = dpp_right0(solb[0].x);
   const v2f ncd = pk_set(-cdown), vb = pk_set(beta);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
@@ -237,53 +183,33 @@ __device__ __forceinline__ void gload_raw(float (&dst)[PXL], const float* __rest
 // stage's state goes to A.tv_out (NULL = not stored), and with A.tv_state_only the combine / store of x_out is skipped.
 // WARM (with CHAIN): the state is the two-field projected dual carried between MYULA iterations (A.tv_warm) instead of the four-field
 // link state -- a template parameter because the L wave's prefetch registers for the state rows set the kernel's VGPR count.
-// TEAMS == 2 (PXL = 4, one launch, no by-products): the image width is split between two teams of waves, each a complete set of roles on its
-// half -- 4 pixels per lane, half the registers per wave, so sixteen waves = four per SIMD are resident, and the second team's roles are placed
-// in reverse order so that the SIMDs carry equal VALU loads (L+T4 | T1+T5 | T2+C | T3+N of one team meet T3+N | T2+C | T1+T5 | L+T4 of the
-// other: 657 ns per tick on every SIMD instead of 710 on the busiest).  The column seam: horizontal neighbours across it come from the other
-// team's LDS rows (x ring, hand-offs) or from a small per-stage seam buffer the edge lanes publish one tick earlier.
-template <int K, int PXL, int KT, bool CHAIN = false, bool WARM = false, int TEAMS = 1>
-__global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (PXL == 8 || CHAIN) ? (WARM ? LMC_WARM_MIN_WAVES : 1) : 2) void myula_step_pipe_kernel(const StepArgs A) {
+template <int K, int PXL, int KT, bool CHAIN = false, bool WARM = false>
+__global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM ? LMC_WARM_MIN_WAVES : 1) : 2) void myula_step_pipe_kernel(const StepArgs A) {
   static_assert(!WARM || CHAIN, "the warm dual uses the state hand-over of the chained launches");
-  static_assert(TEAMS == 1 || (TEAMS == 2 && PXL == 4 && !CHAIN), "two teams: 4 pixels per lane, single launch");
   using G = PipeGeom<K>;
   using L = PipeLds<K, PXL, CHAIN>;
   constexpr int D = G::D, E = G::E, RB = G::RB, NT = G::NT, BW = L::BW, HW = KT > 0 ? (KT - 1) / 2 : 0;
-  constexpr int WPT = NT + 3;                      // waves per team
   static_assert(K >= 1, "at least one dual iteration");
-  static_assert(D >= KT + (TEAMS == 2 ? 2 : 1), "the blur pipeline reads ring rows at least one tick old");
-  extern __shared__ float lds_all[];
+  static_assert(D >= KT + 1, "the blur pipeline reads ring rows at least one tick old");
+  extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int team = TEAMS == 2 ? (wv >= WPT ? 1 : 0) : 0;
-  const int wave = (TEAMS == 2 && team) ? (WPT - 1) - (wv - WPT) : wv;     // role index: 0 L, 1..NT T, NT+1 C, NT+2 N (team 1: reversed order)
-  float* const lds = lds_all + team * L::total;            // this team's rows
-  const float* const ldsO = lds_all + (team ^ 1) * L::total;   // the other team's (seam reads)
-  constexpr int SEAM = NT * 8 + 8;                 // per team: [NT][2 parities][4] edge values of the TV waves, then [2][4] of the blur wave
-  float* const seamT = lds_all + TEAMS * L::total + team * SEAM;           // published by this team's edge lanes
-  const float* const seamO = lds_all + TEAMS * L::total + (team ^ 1) * SEAM;   // published by the other team's
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int chain = blockIdx.x;
   const int H = A.H, W = A.W;
-  const int Wt = W / TEAMS;                        // columns per team
-  const int c0 = team * Wt + lane * PXL;           // global column of the lane's first pixel
-  const int Wl = team * Wt + Wt;                   // this team's columns end here (W when there is one team)
-  const bool seamR = TEAMS == 2 && team == 0 && lane == Wt / PXL - 1;     // right-hand neighbour of this lane's last pixel is the other team's
-  const bool seamL = TEAMS == 2 && team == 1 && lane == 0;                // left-hand neighbour of this lane's first pixel is the other team's
+  const int c0 = lane * PXL;
   const size_t img = (size_t)H * W;
   const float* __restrict__ xin = A.x_in + (size_t)chain * img;
   float* __restrict__ xout = A.x_out + (size_t)chain * img;
 
-  for (int e = threadIdx.x; e < TEAMS * L::total + (TEAMS == 2 ? 2 * SEAM : 0); e += blockDim.x) lds_all[e] = 0.f;   // ring rows < 0, hand-offs of tick -1, g
+  for (int e = threadIdx.x; e < L::o_slab; e += blockDim.x) lds[e] = 0.f;   // ring rows < 0, hand-offs of tick -1, g
   __syncthreads();
 
   const int T_end = (H + D + 3) & ~3;          // ticks, rounded up to the unroll factor (extra ticks write nothing)
   float* const xring = lds + L::o_x;
   auto ring_row = [&](int row) -> float* { return xring + ((unsigned)(row + RB) % (unsigned)RB) * BW; };   // row >= -RB
-  auto ring_row_o = [&](int row) -> const float* { return ldsO + L::o_x + ((unsigned)(row + RB) % (unsigned)RB) * BW; };   // the other team's copy
-  constexpr int LAGT = TEAMS == 2 ? 1 : 0;     // two teams: the residual row is formed one tick before its horizontal adjoint (its seam values travel through LDS)
 
 #ifdef LMC_EXP_SKIP   // timing experiment (with LMC_EXP_NOBARRIER): the waves in the bitmask leave at once (results are wrong)
-  if ((LMC_EXP_SKIP >> wv) & 1) return;
+  if ((LMC_EXP_SKIP >> wave) & 1) return;
 #endif
   // Issue arbitration on the shared SIMDs: the short, latency-bound waves everybody waits for at the barrier (L publishes the
   // ring row, C frees the hand-off slot) go first, the TV waves next, the Philox wave -- pure arithmetic, a quad row-group ahead
@@ -314,15 +240,15 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
 #pragma unroll
       for (int k = 0; k < PXL; ++k) { hxw[a][k] = 0.f; hrw[a][k] = 0.f; }
 #pragma unroll
-    for (int u = 0; u < kXPF; ++u) gload_raw<PXL>(xpre[u], xin + (size_t)min(u, H - 1) * W, c0, Wl);
+    for (int u = 0; u < kXPF; ++u) gload_raw<PXL>(xpre[u], xin + (size_t)min(u, H - 1) * W, c0, W);
     // Vector-memory loads return in order: waiting for a load also waits for every load issued before it.  So the loads a tick
     // consumes must be the OLDEST in flight: y rows are requested three ticks ahead and, inside a tick, before the x row that is only
     // needed four ticks later (with y one tick ahead and issued after x, every tick waited for a fresh HBM access: ~2000 cycles).
     if constexpr (KT > 0) {   // observation rows of the first kYPF residual rows
 #pragma unroll
       for (int u = 0; u < kYPF; ++u) {
-        const int r = u + 1 - D + (KT - 1) - HW + LAGT;
-        gload_raw<PXL>(ypre[u], A.y + (size_t)min(max(r, 0), H - 1) * W, c0, Wl);
+        const int r = u + 1 - D + (KT - 1) - HW;
+        gload_raw<PXL>(ypre[u], A.y + (size_t)min(max(r, 0), H - 1) * W, c0, W);
       }
     }
     // Without a blur: pointwise data terms (identity, diagonal mask).  Their gradient sigma_f m (m x - y) of row t + 1 - D -- the row the
@@ -340,8 +266,8 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
 #pragma unroll
         for (int u = 0; u < kYPF; ++u) {
           const size_t ro = (size_t)min(max(u + 1 - D, 0), H - 1) * W;
-          gload_raw<PXL>(ypre[u], A.y + ro, c0, Wl);
-          if (pw_mask) gload_raw<PXL>(mpre[u], A.mask + ro, c0, Wl);
+          gload_raw<PXL>(ypre[u], A.y + ro, c0, W);
+          if (pw_mask) gload_raw<PXL>(mpre[u], A.mask + ro, c0, W);
         }
       }
     }
@@ -357,29 +283,26 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
         const int rs = u - E - 1;
 #pragma unroll
         for (int f = 0; f < nsf; ++f)
-          gload_row<PXL>(spre[u][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, Wl, sin && rs >= 0 && rs < H);
+          gload_row<PXL>(spre[u][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H);
       }
     }
     double facc = 0.0;        // sum of squared residuals (A.f_out)
-    float Rprev[TEAMS == 2 ? PXL : 1];      // two teams: last tick's residual row (see LAGT)
-#pragma unroll
-    for (int k = 0; k < (TEAMS == 2 ? PXL : 1); ++k) Rprev[k] = 0.f;
     auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
       constexpr int U = decltype(uu)::value, P = U & 1;
       if constexpr (KT > 0) {   // observation row of the residual row kYPF ticks from now
-        const int r3 = t + kYPF + 1 - D + (KT - 1) - HW + LAGT;
-        gload_raw<PXL>(ypre[(U + kYPF) & 3], A.y + (size_t)min(max(r3, 0), H - 1) * W, c0, Wl);
+        const int r3 = t + kYPF + 1 - D + (KT - 1) - HW;
+        gload_raw<PXL>(ypre[(U + kYPF) & 3], A.y + (size_t)min(max(r3, 0), H - 1) * W, c0, W);
       } else if (pw_id || pw_mask) {
         const size_t ro = (size_t)min(max(t + kYPF + 1 - D, 0), H - 1) * W;
-        gload_raw<PXL>(ypre[(U + kYPF) & 3], A.y + ro, c0, Wl);
-        if (pw_mask) gload_raw<PXL>(mpre[(U + kYPF) & 3], A.mask + ro, c0, Wl);
+        gload_raw<PXL>(ypre[(U + kYPF) & 3], A.y + ro, c0, W);
+        if (pw_mask) gload_raw<PXL>(mpre[(U + kYPF) & 3], A.mask + ro, c0, W);
       }
       {   // row t arrives: publish it in the ring (zeros below the image); fetch row t + 4
         float xv[PXL];
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) xv[k] = (t < H && c0 + (k & ~3) < Wl) ? xpre[U][k] : 0.f;
+        for (int k = 0; k < PXL; ++k) xv[k] = (t < H && c0 + (k & ~3) < W) ? xpre[U][k] : 0.f;
         prow_store<PXL>(ring_row(t), lane, xv);
-        gload_raw<PXL>(xpre[U], xin + (size_t)min(t + kXPF, H - 1) * W, c0, Wl);
+        gload_raw<PXL>(xpre[U], xin + (size_t)min(t + kXPF, H - 1) * W, c0, W);
       }
       if constexpr (CHAIN) {   // dual state row t - E - 1 of the previous link -> stage 1's hand-off slot P (read next tick)
         float* hb = lds + L::o_hand0 + P * 4 * BW;
@@ -388,10 +311,10 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
         const int rs = t + 2 - E - 1;
 #pragma unroll
         for (int f = 0; f < nsf; ++f)
-          gload_row<PXL>(spre[P][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, Wl, sin && rs >= 0 && rs < H);
+          gload_row<PXL>(spre[P][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H);
       }
       if constexpr (KT > 0) {
-      const int i = t + 1 - D + (KT - 1) + LAGT;       // blur input row (<= t-1: published in an earlier tick)
+      const int i = t + 1 - D + (KT - 1);       // blur input row (<= t-1: published in an earlier tick)
       float hxn[PXL];
       {
         float xi[PXL], e[PXL + 2 * HW];
@@ -402,15 +325,6 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
         for (int k = 0; k < PXL; ++k) e[HW + k] = xi[k];
 #pragma unroll
         for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_right0(xi[m]);
-        if constexpr (TEAMS == 2) {       // across the seam: the other team's copy of the same ring row (PXL = 4: column c at index c)
-          const float* ro = ring_row_o(i);
-#pragma unroll
-          for (int m = 0; m < HW; ++m) {
-            const float fromA = ro[Wt - HW + m], fromB = ro[m];
-            if (seamL) e[m] = fromA;
-            if (seamR) e[HW + PXL + m] = fromB;
-          }
-        }
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
           float acc = uv[kMaxBlur] * e[k + 2 * HW];
@@ -428,7 +342,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
           float acc = uv[0] * hxn[k];
 #pragma unroll
           for (int a = 1; a < KT; ++a) acc = fmaf(uv[a], hxw[kRing4 ? ((U - a) & 3) : a - 1][k], acc);
-          R[k] = (rowok && c0 + (k & ~3) < Wl) ? acc - ypre[U & 3][k] : 0.f;
+          R[k] = (rowok && c0 + (k & ~3) < W) ? acc - ypre[U & 3][k] : 0.f;
         }
         if (A.f_out) {
 #pragma unroll
@@ -443,16 +357,6 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
 #pragma unroll
         for (int k = 0; k < PXL; ++k) hxw[kRing4 ? (U & 3) : 0][k] = hxn[k];
       }
-      if constexpr (TEAMS == 2) {   // publish this tick's residual edge columns for the other team; the adjoint below runs on LAST tick's row
-        float* se = seamT + NT * 8 + P * 4;
-#pragma unroll
-        for (int m = 0; m < HW; ++m) {
-          if (seamR) se[m] = R[PXL - HW + m];       // team 0: its last HW columns
-          if (seamL) se[m] = R[m];                  // team 1: its first HW columns
-        }
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) { const float tmp = R[k]; R[k] = Rprev[k]; Rprev[k] = tmp; }
-      }
       {   // horizontal adjoint, then G[r - HW] = sum_a u[a] hR[r - 2HW + a]
         float e[PXL + 2 * HW], gout[PXL];
 #pragma unroll
@@ -461,15 +365,6 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
         for (int k = 0; k < PXL; ++k) e[HW + k] = R[k];
 #pragma unroll
         for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_right0(R[m]);
-        if constexpr (TEAMS == 2) {       // the other team's edge columns of the same residual row, published one tick ago
-          const float* so = seamO + NT * 8 + (P ^ 1) * 4;
-#pragma unroll
-          for (int m = 0; m < HW; ++m) {
-            const float v = so[m];
-            if (seamL) e[m] = v;
-            if (seamR) e[HW + PXL + m] = v;
-          }
-        }
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
           float hrn = uv[kMaxBlur] * e[k];
@@ -497,7 +392,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
 #pragma unroll
           for (int k = 0; k < PXL; ++k) {
             float g = 0.f;
-            if (rowok && c0 + (k & ~3) < Wl) {
+            if (rowok && c0 + (k & ~3) < W) {
               if (pw_id) g = A.sigma_f * (xi[k] - ypre[U & 3][k]);
               else g = A.sigma_f * mpre[U & 3][k] * fmaf(mpre[U & 3][k], xi[k], -ypre[U & 3][k]);
             }
@@ -570,7 +465,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
         if (sout && brow >= 0 && brow < H) {             // ... and the dual state of row brow for the next link / iteration
 #pragma unroll
           for (int g = 0; g < NP / 2; ++g) {
-            if (c0 + 4 * g < Wl) {
+            if (c0 + 4 * g < W) {
               float* d = sout + (size_t)brow * W + c0 + 4 * g;
               const float4 vp = make_float4(out.p[2 * g].x, out.p[2 * g].y, out.p[2 * g + 1].x, out.p[2 * g + 1].y);
               const float4 vq = make_float4(out.q[2 * g].x, out.q[2 * g].y, out.q[2 * g + 1].x, out.q[2 * g + 1].y);
@@ -591,73 +486,13 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
     auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
       constexpr int P = decltype(uu)::value & 1;
       const int a2 = t - E - 2 * k2, a1 = t - E - 2 * k1;
-#if LMC_PIPE_SCHED
-      if constexpr (!CHAIN && !SINGLE && NP >= 2) {
-        // (1) everything stage k1 will read is requested first: the previous wave's hand-off rows (written last tick) and the x row
-        //     (into a spare register row: stage k2 below still reads the old xk[P]); (2) stage k2, whose inputs are registers, runs
-        //     while those reads land, and hands its output over group by group; (3) stage k1 finds its inputs in registers.
-        v2f xkn[NP];
-        if constexpr (!FIRST) {
-          if (k1 > 1) {
-            const float* hb = hin + (P ^ 1) * 4 * BW;
-            pairs_load<NP>(inb[P].rr, hb, lane);
-            pairs_load<NP>(inb[P].ss, hb + BW, lane);
-            pairs_load<NP>(inb[P].p, hb + 2 * BW, lane);
-            pairs_load<NP>(inb[P].q, hb + 3 * BW, lane);
-          }
-        }
-        pairs_load<NP>(xkn, ring_row(a1), lane);
-        __builtin_amdgcn_sched_barrier(0);
-        {
-          const float cdown = ((unsigned)(a2 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
-          pipe_stage_emit<NP>(xk[P], o1[P ^ 1].rr, o1[P ^ 1].ss, o1[P], sol2, gam, cdown, cstep, cr_last, beta2, hout + P * 4 * BW, BW, lane);
-        }
-#pragma unroll
-        for (int k = 0; k < NP; ++k) xk[P][k] = xkn[k];
-        {
-          const float cdown = ((unsigned)(a1 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
-          if constexpr (FIRST) pipe_stage_first<NP>(xk[P], sol1, cdown, cstep, cr_last, beta1, o1[P]);
-          else pipe_stage<NP>(xk[P], inb[P].rr, inb[P].ss, inb[P ^ 1], sol1, gam, cdown, cstep, cr_last, beta1, o1[P]);
-        }
-        PIPE_TICK_SYNC();
-        return;
-      }
-#endif
-#ifdef LMC_EXP_EARLY_HANDOFF
-      // the hand-off rows for stage k1 (written by the previous wave last tick) are requested before stage k2's arithmetic, which needs
-      // registers only: their LDS latency hides behind it instead of stalling the wave between the two stages
-      if constexpr (!FIRST) {
-        if (k1 > 1 || from_state) {
-          const float* hb = hin + (P ^ 1) * 4 * BW;
-          pairs_load<NP>(inb[P].rr, hb, lane);
-          pairs_load<NP>(inb[P].ss, hb + BW, lane);
-          if (from_state && warm) {
-#pragma unroll
-            for (int k = 0; k < NP; ++k) { inb[P].p[k] = inb[P].rr[k]; inb[P].q[k] = inb[P].ss[k]; }
-          } else {
-            pairs_load<NP>(inb[P].p, hb + 2 * BW, lane);
-            pairs_load<NP>(inb[P].q, hb + 3 * BW, lane);
-          }
-        }
-      }
-#endif
-      // two teams: the edge lanes' horizontal neighbours across the column seam (published by the other team one tick ago; see PipeSeam)
-      PipeSeam sm1 = no_seam(), sm2 = no_seam();
-      if constexpr (TEAMS == 2) {
-        const float* so = seamO + (wave - 1) * 8 + (P ^ 1) * 4;
-        sm2 = PipeSeam{seamL, seamR, so[0], so[2]};                 // stage k2: ss edge of the other team's stage-k1 output, its sol2 edge
-        float ssl1 = 0.f;
-        if (k1 > 1) ssl1 = (ldsO + L::o_hand + (wave - 2) * 8 * BW + (P ^ 1) * 4 * BW + BW)[Wt - 1];   // stage k1: the other team's hand-off row (ss field)
-        sm1 = PipeSeam{seamL, seamR, ssl1, so[1]};
-      }
       if constexpr (!SINGLE) {   // stage k2 on row a2: inputs are this wave's stage k1, one tick (row a2) and two ticks (row a2-1) old
         const float cdown = ((unsigned)(a2 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
         DualRow<NP> out;
-        pipe_stage<NP>(xk[P], o1[P ^ 1].rr, o1[P ^ 1].ss, o1[P], sol2, gam, cdown, cstep, cr_last, beta2, out, sm2);
+        pipe_stage<NP>(xk[P], o1[P ^ 1].rr, o1[P ^ 1].ss, o1[P], sol2, gam, cdown, cstep, cr_last, beta2, out);
         emit(out, P, a2 - 1);
       }
       {   // stage k1 on row a1: inputs from the previous wave's hand-off (row a1) and the one read a tick earlier (row a1-1)
-#ifndef LMC_EXP_EARLY_HANDOFF
         if constexpr (!FIRST) {
           if (k1 > 1 || from_state) {
             const float* hb = hin + (P ^ 1) * 4 * BW;
@@ -672,17 +507,11 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
             }
           }
         }
-#endif
         pairs_load<NP>(xk[P], ring_row(a1), lane);      // read two ticks ago as row a1 = this tick's a2: consumed above
         const float cdown = ((unsigned)(a1 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
-        if constexpr (FIRST) pipe_stage_first<NP>(xk[P], sol1, cdown, cstep, cr_last, beta1, o1[P], sm1);
-        else pipe_stage<NP>(xk[P], inb[P].rr, inb[P].ss, inb[P ^ 1], sol1, gam, cdown, cstep, cr_last, beta1, o1[P], sm1);
+        if constexpr (FIRST) pipe_stage_first<NP>(xk[P], sol1, cdown, cstep, cr_last, beta1, o1[P]);
+        else pipe_stage<NP>(xk[P], inb[P].rr, inb[P].ss, inb[P ^ 1], sol1, gam, cdown, cstep, cr_last, beta1, o1[P]);
         if constexpr (SINGLE) emit(o1[P], P, a1 - 1);
-      }
-      if constexpr (TEAMS == 2) {   // publish this tick's edge values for the other team's next tick
-        float* se = seamT + (wave - 1) * 8 + P * 4;
-        if (seamR) se[0] = o1[P].ss[NP - 1].y;
-        if (seamL) { se[1] = sol1[0].x; se[2] = sol2[0].x; }
       }
       PIPE_TICK_SYNC();
     };
@@ -751,7 +580,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int r = u - D;
-        gload_raw<PXL>(exq[u], A.extra + (size_t)chain * img + (size_t)min(max(r, 0), H - 1) * W, c0, Wl);
+        gload_raw<PXL>(exq[u], A.extra + (size_t)chain * img + (size_t)min(max(r, 0), H - 1) * W, c0, W);
       }
     }
     auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
@@ -761,7 +590,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
       if (CHAIN && A.tv_state_only) { PIPE_TICK_SYNC(); return; }     // this link only advances the dual state
       if (A.extra) {
         const int r3 = o + 3;
-        gload_raw<PXL>(exq[(U + 3) & 3], A.extra + (size_t)chain * img + (size_t)min(max(r3, 0), H - 1) * W, c0, Wl);
+        gload_raw<PXL>(exq[(U + 3) & 3], A.extra + (size_t)chain * img + (size_t)min(max(r3, 0), H - 1) * W, c0, W);
       }
       float css[PXL], xo[PXL], gv[PXL], prox[PXL];
       prow_load<PXL>(crr[P], hin + (P ^ 1) * HSTR, lane);            // rr^K on row o (written last tick)
@@ -773,11 +602,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
 #pragma unroll
         for (int j = 0; j < PXL; ++j) gv[j] = 0.f;
       }
-      float ssl0 = dpp_left0(css[PXL - 1]);
-      if constexpr (TEAMS == 2) {       // across the seam: the other team's last column of ss^K, from its hand-off row
-        const float v = (ldsO + L::o_hand + (NT - 1) * 8 * BW + (P ^ 1) * HSTR + BW)[Wt - 1];
-        if (seamL) ssl0 = v;
-      }
+      const float ssl0 = dpp_left0(css[PXL - 1]);
 #pragma unroll
       for (int j = 0; j < PXL; ++j) {
         const float ssl = j == 0 ? ssl0 : css[j - 1];
@@ -816,7 +641,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
         const size_t go = (size_t)o * W;
 #pragma unroll
         for (int g = 0; g < PXL / 4; ++g) {
-          if (c0 + 4 * g < Wl) {
+          if (c0 + 4 * g < W) {
             float xi[4] = {0.f, 0.f, 0.f, 0.f}, ex[4] = {0.f, 0.f, 0.f, 0.f};
             if (A.noise_mode == LMC_NOISE_PHILOX) {
 #pragma unroll
@@ -852,10 +677,10 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3) * TEAMS, TEAMS == 2 ? 4 : (P
 template <int K, int PXL, int KT, bool CHAIN = false>
 static constexpr size_t pipe_lds_bytes() { return sizeof(float) * (size_t)PipeLds<K, PXL, CHAIN>::total; }
 
-template <int PXL, int KT, bool CHAIN, int K = 10, bool WARM = false, int TEAMS = 1>
+template <int PXL, int KT, bool CHAIN, int K = 10, bool WARM = false>
 static hipError_t pipe_launch_one(const StepArgs& a, hipStream_t st) {
-  auto kern = myula_step_pipe_kernel<K, PXL, KT, CHAIN, WARM, TEAMS>;
-  constexpr size_t lb = TEAMS * pipe_lds_bytes<K, PXL, KT, CHAIN>() + (TEAMS == 2 ? sizeof(float) * 2 * (((K + 1) / 2) * 8 + 8) : 0);
+  auto kern = myula_step_pipe_kernel<K, PXL, KT, CHAIN, WARM>;
+  constexpr size_t lb = pipe_lds_bytes<K, PXL, KT, CHAIN>();
   static bool attr_set[64] = {};        // per device: the attribute belongs to the function's code object on that device
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -865,16 +690,8 @@ static hipError_t pipe_launch_one(const StepArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.C), dim3(64 * ((K + 1) / 2 + 3) * TEAMS), lb, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.C), dim3(64 * ((K + 1) / 2 + 3)), lb, st, a);
   return hipGetLastError();
-}
-
-// two teams of 4-pixel waves on a 264..512-wide image (K = 10, no by-products): see the kernel's TEAMS parameter
-template <int K>
-static hipError_t pipe_dispatch_teams(const StepArgs& a, int KT, hipStream_t st) {
-  if (KT == 5) return pipe_launch_one<4, 5, false, K, false, 2>(a, st);
-  if (KT == 7) return pipe_launch_one<4, 7, false, K, false, 2>(a, st);
-  return pipe_launch_one<4, 0, false, K, false, 2>(a, st);
 }
 
 // one launch with K dual iterations: blur taps 5 / 7 / none (KT), 8 pixels per lane above 256 columns, else 4
