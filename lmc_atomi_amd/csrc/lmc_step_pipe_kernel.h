@@ -26,6 +26,8 @@ namespace lmc {
 // 4183175 (1.811 ms).  Base: 1.749 ms.
 #ifdef LMC_EXP_NOBARRIER   // timing experiment: waves free-run (results are wrong)
 #define PIPE_TICK_SYNC() do {} while (0)
+#elif defined(LMC_EXP_SLEEP_MASK)   // timing experiment: the waves in the mask start every tick LMC_EXP_SLEEP_N x 64 cycles late (phase shift)
+#define PIPE_TICK_SYNC() do { __syncthreads(); if ((LMC_EXP_SLEEP_MASK >> wave) & 1) __builtin_amdgcn_s_sleep(LMC_EXP_SLEEP_N); } while (0)
 #else
 #define PIPE_TICK_SYNC() __syncthreads()
 #endif
