@@ -13,6 +13,7 @@
 #include "lmc_device.h"
 #include "lmc_launch.h"
 
+#include <cmath>
 #include <cstdlib>
 
 namespace lmc {
@@ -51,10 +52,16 @@ __device__ __forceinline__ void rows_load_raw(float (&dst)[PXL], const float* __
   }
 }
 
-template <int PXL, int KT, bool DOT = false>
+// ULO >= 0: UNIFORM-BOX form (the reference's only blurs: ones(k, k) / k^2, prox_lmc_deconv.py:55-69).  The centred taps are c_u on [ULO, UHI] and zero
+// elsewhere (same window for rows and columns), so every 1-D pass is a sliding window sum: 2 operations per pixel instead of KT (horizontal: the
+// first pixel of a lane directly, the next ones by +new -old; vertical: a running sum over a ring of the horizontally filtered rows, re-formed
+// directly every 8th row so that rounding cannot drift).  The scale c_u^2 c_v^2 sigma_f is applied once.  Same update to rounding (tests).
+template <int PXL, int KT, bool DOT = false, int ULO = -1, int UHI = -1>
 __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step_rows_kernel(const StepArgs P, const int band_rows, const int nbands) {
   using Gm = RowsGeom<PXL, KT>;
   constexpr int HW = Gm::HW, LAG = Gm::LAG, PF = Gm::PF;
+  constexpr bool UNI = ULO >= 0;
+  static_assert(!UNI || (UHI >= ULO && UHI < KT && !DOT), "uniform-box window");
   if constexpr (DOT) {
     if (P.skip_flag && *P.skip_flag) return;            // CG operator apply after convergence (lmc_capi.hip: cg_solve_fused)
   }
@@ -78,7 +85,13 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   constexpr bool kNzLds = PXL == 8;
   __shared__ float nz_lds[kNzLds ? 4 * PXL * 4 * 64 : 1];
   float* const nzw = nz_lds + (kNzLds ? (threadIdx.x >> 6) * PXL * 4 * 64 + lane : 0);
+  // general taps: A / G = residual / gradient accumulators of 8 rows in flight; uniform box: A / G = rings of the horizontally filtered rows
+  // (of x / of the residual), Vs / Ws = the running vertical window sums
   float xr[8][PXL], A[8][PXL], G[8][PXL], nz[kNzLds ? 1 : PXL][4], yq[4][PXL];
+  float Vs[UNI ? PXL : 1], Ws[UNI ? PXL : 1];
+#pragma unroll
+  for (int k = 0; k < (UNI ? PXL : 1); ++k) Vs[k] = Ws[k] = 0.f;
+  const float cbox = UNI ? P.blur.h[ULO] * P.blur.h[kMaxBlur + ULO] : 0.f;       // c_u c_v
 #pragma unroll
   for (int s = 0; s < 8; ++s)
 #pragma unroll
@@ -130,6 +143,14 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
         for (int k = 0; k < PXL; ++k) e[HW + k] = xm[k];
 #pragma unroll
         for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_right0(xm[m]);
+        if constexpr (UNI) {     // window sum of e[k + 2HW - UHI .. k + 2HW - ULO]
+          float acc = e[2 * HW - UHI];
+#pragma unroll
+          for (int j = 2 * HW - UHI + 1; j <= 2 * HW - ULO; ++j) acc += e[j];
+          hx[0] = acc;
+#pragma unroll
+          for (int k = 1; k < PXL; ++k) hx[k] = (hx[k - 1] + e[k + 2 * HW - ULO]) - e[k - 1 + 2 * HW - UHI];
+        } else {
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
           float acc = uv[kMaxBlur] * e[k + 2 * HW];
@@ -137,7 +158,29 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
           for (int b = 1; b < KT; ++b) acc = fmaf(uv[kMaxBlur + b], e[k + 2 * HW - b], acc);
           hx[k] = acc;
         }
+        }
       }
+      const int r = i - HW;
+      float R[PXL];
+      if constexpr (UNI) {
+        // (2u) ring of filtered rows; vertical window of residual row r: filtered rows i - UHI .. i - ULO
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) A[J][k] = hx[k];
+        if constexpr (J == 0) {          // re-form the sum directly (bounds the rounding drift of the running update)
+#pragma unroll
+          for (int k = 0; k < PXL; ++k) {
+            float acc = A[(J - ULO + 8) & 7][k];
+            static_for<ULO + 1, UHI + 1>([&](auto aa) { acc += A[(J - decltype(aa)::value + 16) & 7][k]; });
+            Vs[k] = acc;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < PXL; ++k) Vs[k] = (Vs[k] + A[(J - ULO + 8) & 7][k]) - A[(J - 1 - UHI + 16) & 7][k];
+        }
+        const bool rowok = r >= 0 && r < H && r >= r0 - HW;      // rows before the band's first residual row: partial windows, kept out
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) R[k] = (rowok && c0 + (k & ~3) < W) ? fmaf(cbox, Vs[k], -yq[J & 3][k]) : 0.f;
+      } else {
       // (2) scatter into the residual accumulators of rows i-HW .. i+HW (the last one starts here)
       static_for<0, KT>([&](auto aa) {
         constexpr int a = decltype(aa)::value;
@@ -146,13 +189,12 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
         for (int k = 0; k < PXL; ++k) A[s][k] = (a == KT - 1) ? uv[a] * hx[k] : fmaf(uv[a], hx[k], A[s][k]);
       });
       // (3) residual row r = i - HW is complete
-      const int r = i - HW;
       constexpr int sr = (J - HW + 8) & 7;
-      float R[PXL];
       {
         const bool rowok = r >= 0 && r < H;
 #pragma unroll
         for (int k = 0; k < PXL; ++k) R[k] = (rowok && c0 + (k & ~3) < W) ? A[sr][k] - yq[J & 3][k] : 0.f;
+      }
       }
       // (4) horizontal adjoint of the residual row
       float hr[PXL];
@@ -164,6 +206,14 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
         for (int k = 0; k < PXL; ++k) e[HW + k] = R[k];
 #pragma unroll
         for (int m = 0; m < HW; ++m) e[HW + PXL + m] = dpp_right0(R[m]);
+        if constexpr (UNI) {     // window sum of e[k + ULO .. k + UHI]
+          float acc = e[ULO];
+#pragma unroll
+          for (int j = ULO + 1; j <= UHI; ++j) acc += e[j];
+          hr[0] = acc;
+#pragma unroll
+          for (int k = 1; k < PXL; ++k) hr[k] = (hr[k - 1] + e[k + UHI]) - e[k - 1 + ULO];
+        } else {
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
           float acc = uv[kMaxBlur] * e[k];
@@ -171,7 +221,26 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
           for (int b = 1; b < KT; ++b) acc = fmaf(uv[kMaxBlur + b], e[k + b], acc);
           hr[k] = acc;
         }
+        }
       }
+      if constexpr (UNI) {
+        // (5u) ring of filtered residual rows (slot = residual row & 7); gradient row o = i - LAG: residual rows o - HW + ULO .. o - HW + UHI
+        constexpr int sR = (J - HW + 8) & 7;                    // slot of residual row r = i - HW
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) G[sR][k] = hr[k];
+        constexpr int sNew = (J - LAG - HW + UHI + 32) & 7, sOld = (J - LAG - 1 - HW + ULO + 32) & 7;
+        if constexpr (J == 0) {
+#pragma unroll
+          for (int k = 0; k < PXL; ++k) {
+            float acc = G[(J - LAG - HW + ULO + 32) & 7][k];
+            static_for<ULO + 1, UHI + 1>([&](auto aa) { acc += G[(J - LAG - HW + decltype(aa)::value + 32) & 7][k]; });
+            Ws[k] = acc;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < PXL; ++k) Ws[k] = (Ws[k] + G[sNew][k]) - G[sOld][k];
+        }
+      } else {
       // (5) scatter into the gradient accumulators of rows r+HW .. r-HW, i.e. i .. i-LAG (the first one starts here)
       static_for<0, KT>([&](auto aa) {
         constexpr int a = decltype(aa)::value;
@@ -179,6 +248,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
 #pragma unroll
         for (int k = 0; k < PXL; ++k) G[s][k] = (a == 0) ? uv[0] * hr[k] : fmaf(uv[a], hr[k], G[s][k]);
       });
+      }
       // (6) output row o = i - LAG
       const int o = i - LAG;
       constexpr int so = (J - LAG + 8) & 7;
@@ -226,7 +296,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const float x = xr[so][4 * g + q];
-              float gr = P.sigma_f * G[so][4 * g + q];
+              float gr = UNI ? (P.sigma_f * cbox) * Ws[4 * g + q] : P.sigma_f * G[so][4 * g + q];
               if (P.extra) gr = fmaf(P.extra_coef, x - ex[q], gr);
               float px = x;
               if (P.prior_kind == LMC_PRIOR_L2) px = x * P.prior_p0;
@@ -343,6 +413,32 @@ hipError_t launch_step_rows(StepArgs a, hipStream_t st) {
     }
     return hipGetLastError();
   }
+  // uniform boxes (all the reference's blurs): the sliding-window form.  Taps constant on one window [lo, hi] -- the same for rows and columns --
+  // and zero elsewhere; LMC_ROWS_UNI=0 keeps the general form (A/B runs).
+  static const bool uni_on = [] { const char* e = getenv("LMC_ROWS_UNI"); return !e || atoi(e) != 0; }();
+  int lo = -1, hi = -1;
+  if (uni_on) {
+    auto window = [&](const float* t, int& l, int& h) {
+      l = -1; h = -1;
+      for (int i = 0; i < KT; ++i) if (t[i] != 0.f) { if (l < 0) l = i; h = i; }
+      if (l < 0) return false;
+      for (int i = l; i <= h; ++i) if (std::fabs(t[i] - t[l]) > 1e-6f * std::fabs(t[l])) return false;
+      return true;
+    };
+    int l2, h2;
+    if (!(window(uc, lo, hi) && window(vc, l2, h2) && l2 == lo && h2 == hi)) lo = hi = -1;
+  }
+#define LMC_ROWS_UNI_LAUNCH(PX, KTT, LO, HI)                                                                                   \
+  if (KT == KTT && lo == LO && hi == HI) {                                                                                   \
+    hipLaunchKernelGGL((myula_step_rows_kernel<PX, KTT, false, LO, HI>), dim3(nblk), dim3(256), 0, st, a, band, nbands);      \
+    return hipGetLastError();                                                                                                \
+  }
+  if (a.W <= 256) {
+    LMC_ROWS_UNI_LAUNCH(4, 5, 0, 4) LMC_ROWS_UNI_LAUNCH(4, 7, 0, 6) LMC_ROWS_UNI_LAUNCH(4, 7, 0, 5)
+  } else {
+    LMC_ROWS_UNI_LAUNCH(8, 5, 0, 4) LMC_ROWS_UNI_LAUNCH(8, 7, 0, 6) LMC_ROWS_UNI_LAUNCH(8, 7, 0, 5)
+  }
+#undef LMC_ROWS_UNI_LAUNCH
   if (a.W <= 256) {
     if (KT == 5) hipLaunchKernelGGL((myula_step_rows_kernel<4, 5>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
     else hipLaunchKernelGGL((myula_step_rows_kernel<4, 7>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
