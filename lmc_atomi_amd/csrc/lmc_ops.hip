@@ -246,12 +246,15 @@ __global__ __launch_bounds__(256) void moments4_bg_kernel(const float* __restric
                                                           double* __restrict__ s1, double* __restrict__ s2) {
   const int lane = threadIdx.x & 63;
   const int sel = lane & 3;
+  // gridDim.y > 1: the chains are split into that many segments (small configurations: more workgroups than 1024-pixel groups)
+  const int seg_len = (C + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int cs = (int)blockIdx.y * seg_len, ce = min(C, cs + seg_len);
   for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
     const size_t p = ((size_t)g * 256 + threadIdx.x) * 4;
-    const int c1 = p < img ? C : 0;
+    const int c1 = p < img ? ce : cs;
     double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
     const float* __restrict__ src = x + p;
-    int c = 0;
+    int c = cs;
     for (; c + 4 <= c1; c += 4) {
       float4 v[4];
 #pragma unroll
@@ -293,8 +296,12 @@ hipError_t launch_moments_bg(const float* x, int C, int H, int W, double* s1, do
   const size_t img = (size_t)H * W;
   if ((img & 3) || n_wg < 1) return launch_moments(x, C, H, W, s1, s2, st);
   const int n_groups = (int)((img / 4 + 255) / 256);
-  if (n_wg > n_groups) n_wg = n_groups;
-  hipLaunchKernelGGL(moments4_bg_kernel, dim3(n_wg), dim3(256), 0, st, x, C, img, n_groups, s1, s2);
+  int nseg = 1;
+  if (n_wg > n_groups) {        // fewer pixel groups than workgroups asked for: split the chains as well (>= 16 chains per segment)
+    while (n_groups * nseg * 2 <= n_wg && nseg * 32 <= C) nseg *= 2;
+    n_wg = n_groups;
+  }
+  hipLaunchKernelGGL(moments4_bg_kernel, dim3(n_wg, nseg), dim3(256), 0, st, x, C, img, n_groups, s1, s2);
   return hipGetLastError();
 }
 
