@@ -56,34 +56,37 @@ def synth_problem(H, W, sigma, seed=0, blur="box"):
     return u, h, y
 
 
-def cpu_baseline(H, W, h, y, sigma, tau_reg, niter_tv, chains=4, iters=20):
+def cpu_baseline(H, W, h, y, sigma, prior, label, mask=None, chains=4, iters=20):
     """The oracle on a bounded sample of the same workload, timed on this host: the C restatement
     (oracle/lmc_oracle_c.c, float64, OpenMP over chains, PCG64 noise from numpy) on up to 16 cores -- the GPU box's CPU
     share for one GPU -- is the reported value; the numpy restatement (the one pinned by the reference's own outputs;
     the two agree bit for bit, tests/test_oracle_c.py) and the C one on a single core are reported beside it.
-    Checker / baseline only -- never on the product path."""
+    The Haar prior exists in the numpy restatement only.  Checker / baseline only -- never on the product path."""
     from oracle import lmc_oracle as O
     from oracle import lmc_oracle_c as OC
     OC.build()
     gamma, tau = sigma ** 2, 0.2 * sigma ** 2
-    prior = {"kind": "tv", "sigma": tau_reg, "niter": niter_tv, "t": gamma}
+    hh, off = (None, None) if mask is not None else (h, (2, 2))
 
     def run(step, n_chains, n_it, **kw):
         rng = np.random.default_rng(0)
         x = np.zeros((n_chains, H, W))
         t0 = time.perf_counter()
         for _ in range(n_it):
-            x = step(x, y, h, (2, 2), 1 / sigma ** 2, tau, gamma, prior, rng.standard_normal(x.shape), **kw)
+            x = step(x, y, hh, off, 1 / sigma ** 2, tau, gamma, prior, rng.standard_normal(x.shape), mask=mask, **kw)
         dt = time.perf_counter() - t0
         return n_chains * n_it / dt, dt
 
     v_np, t_np = run(O.myula_step, chains, max(1, iters // 2))
+    if prior["kind"] == "haar":
+        return {"value": v_np, "unit": "chain-it/s", "cores": 1, "kind": "port",
+                "sample": f"{chains} chains x {max(1, iters // 2)} iterations of the same {H}x{W} {label} workload, oracle/lmc_oracle.py float64 numpy on one core, {t_np:.1f} s"}
     v_c1, t_c1 = run(OC.myula_step, chains, iters, threads=1)
     T = max(1, min(16, os.cpu_count() or 1, OC.max_threads()))
     mc, mi = 4 * T, 2 * iters
     v_mt, t_mt = run(OC.myula_step, mc, mi, threads=T)
     return {"value": v_mt, "unit": "chain-it/s", "cores": T, "kind": "port",
-            "sample": f"{mc} chains x {mi} iterations of the same {H}x{W} MYULA-TV(K={niter_tv}) workload, "
+            "sample": f"{mc} chains x {mi} iterations of the same {H}x{W} {label} workload, "
                       f"oracle/lmc_oracle_c.c float64 with {T} OpenMP threads, {t_mt:.1f} s on {T} of {os.cpu_count()} host cores",
             "one_core": {"c": v_c1, "numpy": v_np, "unit": "chain-it/s",
                          "sample": f"{chains} chains x {iters} (C, {t_c1:.1f} s) / {max(1, iters // 2)} (numpy, {t_np:.1f} s) iterations"}}
@@ -117,9 +120,16 @@ def main():
     ap.add_argument("--tv-lagged", action="store_true", help="TV prox after tv_iters - 1 dual updates (lmc_problem.tv_lagged_output)")
     ap.add_argument("--no-hbm-probe", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
+                    help="BASELINE.json configuration by number (per-GPU shard): 2 = 256x256 deblur + l2 prior, 128 chains; 3 / 4 = 512x512 deblur + TV K=10, "
+                         "1024 chains per GPU (the default; 4 = the same over 8 GPUs); 5 = 512x512 inpainting mask + Haar-l1 prior, 512 chains per GPU")
     ap.add_argument("--cpu-chains", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=20)
     args = ap.parse_args()
+    if args.config == 2:
+        args.size, args.chains, args.prior = 256, 128, "l2"
+    elif args.config == 5:
+        args.size, args.chains, args.prior, args.data = 512, 512, "haar", "mask"
 
     # stdout carries ONE JSON line and nothing else: libraries that print banners on fd 1 (RCCL's version block at communicator set-up)
     # are sent to stderr for the whole run; the line itself goes to the saved descriptor
@@ -323,8 +333,19 @@ def main():
         if args.alg == "mymala":
             out["config"]["acceptance_rate_mean"] = float(smp.acceptance_rate().mean())
             out["config"]["tau_scale"] = args.tau_scale
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(H, W, h, y, sigma, tau_reg, args.tv_iters, args.cpu_chains, args.cpu_iters)
+        if world == 1 and not args.no_cpu_baseline and args.alg == "myula" and args.ncvx == "none" and not args.tv_warm:
+            oprior = {"tv": {"kind": "tv", "sigma": tau_reg, "niter": args.tv_iters - (1 if args.tv_lagged else 0), "t": gamma},
+                      "l2": {"kind": "l2", "sigma": 0.05, "t": gamma}, "l1": {"kind": "l1", "sigma": tau_reg, "t": gamma},
+                      "haar": {"kind": "haar", "sigma": tau_reg, "t": gamma}}[args.prior]
+            if args.data == "blur":
+                oy, omask, oh = y, None, h
+            elif args.data == "mask":
+                omask = (np.random.default_rng(7).uniform(size=(H, W)) < 0.6).astype(np.float64)
+                oy, oh = omask * u, None
+            else:
+                oy, omask, oh = y, None, None
+            label = f"MYULA {args.data} + {args.prior}" + (f"(K={args.tv_iters})" if args.prior == "tv" else "")
+            out["cpu_baseline"] = cpu_baseline(H, W, oh, oy, sigma, oprior, label, mask=omask, chains=args.cpu_chains, iters=args.cpu_iters)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     smp.close()
