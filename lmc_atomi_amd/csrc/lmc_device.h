@@ -127,6 +127,37 @@ __device__ __forceinline__ float dpp_from_right(float v, float edge) {  // lane 
 }
 
 // wave shifts with zero fill through bound_ctrl: no "old" register to initialise (one v_mov less per shift)
+// ---- rows that start on 4-byte boundaries only (W % 4 != 0, e.g. the reference's 667 x 877 image) ---------------------------------------
+// gfx950 under ROCm runs with unaligned access enabled: a 16-byte global access needs dword alignment only, and the compiler emits
+// global_load/store_dwordx4 for a 4-byte-aligned vector type.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// Pixels c .. c+3 of a row of W >= 4 floats -> d[0..3], one 16-byte access that never leaves the row: the group that holds the row end
+// (c < W < c + 4) reads the last four floats of the row and moves them down by 4 - W % 4 (wave-uniform) places; a group past the row reads its
+// start.  Elements at columns >= W come back undefined: every caller masks per pixel.
+__device__ __forceinline__ void load4_dword_aligned(float& d0, float& d1, float& d2, float& d3, const float* __restrict__ row, int c, int W) {
+  const bool part = c < W && c + 4 > W;
+  const int cc = c + 4 <= W ? c : (part ? W - 4 : 0);
+  const f4u v = *reinterpret_cast<const f4u*>(row + cc);
+  const int s = 4 - (W & 3);
+  d0 = part ? (s == 1 ? v.y : (s == 2 ? v.z : v.w)) : v.x;
+  d1 = part ? (s == 1 ? v.z : v.w) : v.y;
+  d2 = part ? v.w : v.z;
+  d3 = v.w;
+}
+// Pixels c .. c+3 -> row, those with columns in [lo, hi) only (hi <= W): one 16-byte store when the group is inside, else pixel by pixel.
+__device__ __forceinline__ void store4_dword_aligned(float* __restrict__ row, int c, int lo, int hi, float v0, float v1, float v2, float v3) {
+  if (c >= lo && c + 4 <= hi) {
+    f4u v; v.x = v0; v.y = v1; v.z = v2; v.w = v3;
+    *reinterpret_cast<f4u*>(row + c) = v;
+  } else {
+    if (c >= lo && c < hi) row[c] = v0;
+    if (c + 1 >= lo && c + 1 < hi) row[c + 1] = v1;
+    if (c + 2 >= lo && c + 2 < hi) row[c + 2] = v2;
+    if (c + 3 >= lo && c + 3 < hi) row[c + 3] = v3;
+  }
+}
+
 __device__ __forceinline__ float dpp_left0(float v) {    // lane i <- v[i-1]; lane 0 <- 0
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }

@@ -98,9 +98,20 @@ struct DualRow { v2f rr[NP], ss[NP], p[NP], q[NP]; };
 
 // One FGP dual iteration on NP pixel pairs per lane.  r1, s1 = (rr, ss)^{k-1} on row a; in0 = (rr, ss, p, q)^{k-1} on row
 // b = a-1; solb = sol^k on row b (in) -> sol^k on row a (out); out = (rr, ss, p, q)^k on row b.
+// The horizontal step coefficient per pixel: -c, and 0 for the pixel in the last image column (no difference across it).  LASTLANE: the image
+// width is a multiple of the pixels per lane, so that pixel is the last one of a lane (cr_last, a per-lane scalar); otherwise it can be any
+// pixel of a lane and the coefficients are a per-lane register array (ncrv).
 template <int NP>
+struct PipeCr { float cstep, cr_last; v2f ncrv[NP]; };
+template <int NP, bool LASTLANE>
+__device__ __forceinline__ v2f pipe_ncr(const PipeCr<NP>& c, int i) {
+  if constexpr (LASTLANE) return i == NP - 1 ? v2f{-c.cstep, -c.cr_last} : pk_set(-c.cstep);
+  else return c.ncrv[i];
+}
+
+template <int NP, bool LASTLANE = true>
 __device__ __forceinline__ void pipe_stage(const v2f (&xa)[NP], const v2f (&r1)[NP], const v2f (&s1)[NP], const DualRow<NP>& in0,
-                                           v2f (&solb)[NP], float gam, float cdown, float cstep, float cr_last, float beta,
+                                           v2f (&solb)[NP], float gam, float cdown, const PipeCr<NP>& cr, float beta,
                                            DualRow<NP>& out) {
   v2f sol[NP];
   const float ssl0 = dpp_left0(s1[NP - 1].y);
@@ -114,7 +125,7 @@ __device__ __forceinline__ void pipe_stage(const v2f (&xa)[NP], const v2f (&r1)[
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const v2f solr = v2f{solb[i].y, i == NP - 1 ? solr_last : solb[i + 1].x};
-    const v2f ncr = i == NP - 1 ? v2f{-cstep, -cr_last} : pk_set(-cstep);
+    const v2f ncr = pipe_ncr<NP, LASTLANE>(cr, i);
     const v2f r = pk_fma(ncd, sol[i] - solb[i], in0.rr[i]);
     const v2f s = pk_fma(ncr, solr - solb[i], in0.ss[i]);
     const v2f n2 = pk_fma(r, r, s * s);
@@ -133,15 +144,15 @@ __device__ __forceinline__ void pipe_stage(const v2f (&xa)[NP], const v2f (&r1)[
 
 // Stage 1 of a launch that starts from the zero dual state: (rr, ss, p, q)^0 = 0, so sol^1 = x and the differences with the previous
 // iterate vanish.  Bit-identical to pipe_stage() fed with zeros (x - 0 = x, fma(c, d, 0) = c*d), at ~60 % of its instructions.
-template <int NP>
-__device__ __forceinline__ void pipe_stage_first(const v2f (&xa)[NP], v2f (&solb)[NP], float cdown, float cstep, float cr_last, float beta,
+template <int NP, bool LASTLANE = true>
+__device__ __forceinline__ void pipe_stage_first(const v2f (&xa)[NP], v2f (&solb)[NP], float cdown, const PipeCr<NP>& cr, float beta,
                                                  DualRow<NP>& out) {
   const float solr_last = dpp_right0(solb[0].x);
   const v2f ncd = pk_set(-cdown), vb = pk_set(beta);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const v2f solr = v2f{solb[i].y, i == NP - 1 ? solr_last : solb[i + 1].x};
-    const v2f ncr = i == NP - 1 ? v2f{-cstep, -cr_last} : pk_set(-cstep);
+    const v2f ncr = pipe_ncr<NP, LASTLANE>(cr, i);
     const v2f r = ncd * (xa[i] - solb[i]);
     const v2f s = ncr * (solr - solb[i]);
     const v2f n2 = pk_fma(r, r, s * s);
@@ -158,26 +169,59 @@ __device__ __forceinline__ void pipe_stage_first(const v2f (&xa)[NP], v2f (&solb
 
 // Row load with zero fill.  The load itself is unconditional (masked-off lanes read the start of the row, always a valid address:
 // callers pass a clamped row) and the mask is applied to the value: a predicated load costs an exec-mask branch per access and
-// splits the tick into basic blocks the scheduler cannot move loads across.
+// splits the tick into basic blocks the scheduler cannot move loads across.  `al`: rows start on 16-byte boundaries (W % 4 == 0): one
+// float4 per group of four pixels; otherwise (any W, e.g. the reference's 667 x 877 image) dword-aligned 16-byte accesses (lmc_device.h) and per-pixel masks.
 template <int PXL>
-__device__ __forceinline__ void gload_row(float (&dst)[PXL], const float* __restrict__ row, int c0, int W, bool ok) {
+__device__ __forceinline__ void gload_row(float (&dst)[PXL], const float* __restrict__ row, int c0, int W, bool ok, bool al = true) {
+  if (al) {
 #pragma unroll
-  for (int g = 0; g < PXL / 4; ++g) {
-    const bool okg = ok && c0 + 4 * g < W;
-    const float4 v = *reinterpret_cast<const float4*>(row + (okg ? c0 + 4 * g : 0));
-    dst[4 * g] = okg ? v.x : 0.f; dst[4 * g + 1] = okg ? v.y : 0.f; dst[4 * g + 2] = okg ? v.z : 0.f; dst[4 * g + 3] = okg ? v.w : 0.f;
+    for (int g = 0; g < PXL / 4; ++g) {
+      const bool okg = ok && c0 + 4 * g < W;
+      const float4 v = *reinterpret_cast<const float4*>(row + (okg ? c0 + 4 * g : 0));
+      dst[4 * g] = okg ? v.x : 0.f; dst[4 * g + 1] = okg ? v.y : 0.f; dst[4 * g + 2] = okg ? v.z : 0.f; dst[4 * g + 3] = okg ? v.w : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < PXL / 4; ++g) {
+      float v[4];
+      load4_dword_aligned(v[0], v[1], v[2], v[3], row, c0 + 4 * g, W);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dst[4 * g + q] = (ok && c0 + 4 * g + q < W) ? v[q] : 0.f;
+    }
   }
 }
 
 // The same without the select: for values that are masked where they are USED (a select at load time makes the wave wait for
-// the prefetch at once).  Lanes past the row read its start.
+// the prefetch at once).  Lanes / pixels past the row read its start.
 template <int PXL>
-__device__ __forceinline__ void gload_raw(float (&dst)[PXL], const float* __restrict__ row, int c0, int W) {
+__device__ __forceinline__ void gload_raw(float (&dst)[PXL], const float* __restrict__ row, int c0, int W, bool al = true) {
+  if (al) {
 #pragma unroll
-  for (int g = 0; g < PXL / 4; ++g) {
-    const float4 v = *reinterpret_cast<const float4*>(row + (c0 + 4 * g < W ? c0 + 4 * g : 0));
-    dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
+    for (int g = 0; g < PXL / 4; ++g) {
+      const float4 v = *reinterpret_cast<const float4*>(row + (c0 + 4 * g < W ? c0 + 4 * g : 0));
+      dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < PXL / 4; ++g) load4_dword_aligned(dst[4 * g], dst[4 * g + 1], dst[4 * g + 2], dst[4 * g + 3], row, c0 + 4 * g, W);
   }
+}
+
+// Four pixels of a row to global memory: columns c .. c + 3, of which those in [lo, hi) are written (the interior of a column strip, and < W).
+__device__ __forceinline__ void gstore4(float* __restrict__ row, int c, int lo, int hi, bool al, float v0, float v1, float v2, float v3) {
+  if (al) {        // W, lo, hi multiples of 4: the group is inside or outside as a whole
+    if (c >= lo && c < hi) *reinterpret_cast<float4*>(row + c) = make_float4(v0, v1, v2, v3);
+  } else store4_dword_aligned(row, c, lo, hi, v0, v1, v2, v3);
+}
+
+// Column strips (images wider than one wave: W > 64 PXL): a workgroup handles the columns [col_start, col_start + 64 PXL) of its chain, of which
+// the interior [strip U, (strip + 1) U) is written; the HALO columns on either side are recomputed, not exchanged: the update of a pixel
+// depends on x within K + 1 columns (one per dual iteration, one for the final divergence) and within 2 HW columns for the blur gradient.
+// Rounded up to the pixels per lane, so that every strip starts on a lane-sized column multiple: 16-byte aligned accesses stay aligned and the
+// last image column of an image whose width is a multiple of PXL stays the last pixel of a lane (LASTLANE) in every strip.
+__host__ __device__ constexpr int pipe_halo(int K, int KT, int PXL) {
+  const int need = (K + 1 > KT - 1 ? K + 1 : KT - 1);
+  return (need + PXL - 1) / PXL * PXL;
 }
 
 // KT = 0: no data term (pure prox, or t = 0).  CHAIN: the launch is one link of a chain of launches that together run more than K
@@ -185,7 +229,9 @@ __device__ __forceinline__ void gload_raw(float (&dst)[PXL], const float* __rest
 // stage's state goes to A.tv_out (NULL = not stored), and with A.tv_state_only the combine / store of x_out is skipped.
 // WARM (with CHAIN): the state is the two-field projected dual carried between MYULA iterations (A.tv_warm) instead of the four-field
 // link state -- a template parameter because the L wave's prefetch registers for the state rows set the kernel's VGPR count.
-template <int K, int PXL, int KT, bool CHAIN = false, bool WARM = false>
+// AL: image rows start on 16-byte boundaries (W % 4 == 0): float4 global accesses; AL = false (any W): pixel-by-pixel accesses with per-pixel bounds
+// (instantiated for K = 10 only: the reference's 667 x 877 image with niter_tv = 10 and the 10-iteration links of its ME-TV term).
+template <int K, int PXL, int KT, bool CHAIN = false, bool WARM = false, bool AL = true>
 __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM ? LMC_WARM_MIN_WAVES : 1) : 2) void myula_step_pipe_kernel(const StepArgs A) {
   static_assert(!WARM || CHAIN, "the warm dual uses the state hand-over of the chained launches");
   using G = PipeGeom<K>;
@@ -198,7 +244,13 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int chain = blockIdx.x;
   const int H = A.H, W = A.W;
-  const int c0 = lane * PXL;
+  // column strip of this workgroup (blockIdx.y; one strip = the whole row when W <= 64 PXL): c0 is a GLOBAL column, LDS rows are indexed by lane
+  constexpr int HALO = pipe_halo(K, KT, PXL);
+  const int strip = blockIdx.y;
+  const int strip_u = gridDim.y > 1 ? BW - 2 * HALO : W;
+  const int c0 = (strip ? strip * strip_u - HALO : 0) + lane * PXL;
+  const int st_lo = strip * strip_u, st_hi = min(W, st_lo + strip_u);       // columns this workgroup writes
+  constexpr bool al = AL;                                                    // rows are 16-byte aligned (strip_u and HALO are multiples of 4)
   const size_t img = (size_t)H * W;
   const float* __restrict__ xin = A.x_in + (size_t)chain * img;
   float* __restrict__ xout = A.x_out + (size_t)chain * img;
@@ -242,7 +294,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
 #pragma unroll
       for (int k = 0; k < PXL; ++k) { hxw[a][k] = 0.f; hrw[a][k] = 0.f; }
 #pragma unroll
-    for (int u = 0; u < kXPF; ++u) gload_raw<PXL>(xpre[u], xin + (size_t)min(u, H - 1) * W, c0, W);
+    for (int u = 0; u < kXPF; ++u) gload_raw<PXL>(xpre[u], xin + (size_t)min(u, H - 1) * W, c0, W, al);
     // Vector-memory loads return in order: waiting for a load also waits for every load issued before it.  So the loads a tick
     // consumes must be the OLDEST in flight: y rows are requested three ticks ahead and, inside a tick, before the x row that is only
     // needed four ticks later (with y one tick ahead and issued after x, every tick waited for a fresh HBM access: ~2000 cycles).
@@ -250,7 +302,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
 #pragma unroll
       for (int u = 0; u < kYPF; ++u) {
         const int r = u + 1 - D + (KT - 1) - HW;
-        gload_raw<PXL>(ypre[u], A.y + (size_t)min(max(r, 0), H - 1) * W, c0, W);
+        gload_raw<PXL>(ypre[u], A.y + (size_t)min(max(r, 0), H - 1) * W, c0, W, al);
       }
     }
     // Without a blur: pointwise data terms (identity, diagonal mask).  Their gradient sigma_f m (m x - y) of row t + 1 - D -- the row the
@@ -268,8 +320,8 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
 #pragma unroll
         for (int u = 0; u < kYPF; ++u) {
           const size_t ro = (size_t)min(max(u + 1 - D, 0), H - 1) * W;
-          gload_raw<PXL>(ypre[u], A.y + ro, c0, W);
-          if (pw_mask) gload_raw<PXL>(mpre[u], A.mask + ro, c0, W);
+          gload_raw<PXL>(ypre[u], A.y + ro, c0, W, al);
+          if (pw_mask) gload_raw<PXL>(mpre[u], A.mask + ro, c0, W, al);
         }
       }
     }
@@ -285,7 +337,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
         const int rs = u - E - 1;
 #pragma unroll
         for (int f = 0; f < nsf; ++f)
-          gload_row<PXL>(spre[u][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H);
+          gload_row<PXL>(spre[u][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H, al);
       }
     }
     double facc = 0.0;        // sum of squared residuals (A.f_out)
@@ -293,18 +345,18 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       constexpr int U = decltype(uu)::value, P = U & 1;
       if constexpr (KT > 0) {   // observation row of the residual row kYPF ticks from now
         const int r3 = t + kYPF + 1 - D + (KT - 1) - HW;
-        gload_raw<PXL>(ypre[(U + kYPF) & 3], A.y + (size_t)min(max(r3, 0), H - 1) * W, c0, W);
+        gload_raw<PXL>(ypre[(U + kYPF) & 3], A.y + (size_t)min(max(r3, 0), H - 1) * W, c0, W, al);
       } else if (pw_id || pw_mask) {
         const size_t ro = (size_t)min(max(t + kYPF + 1 - D, 0), H - 1) * W;
-        gload_raw<PXL>(ypre[(U + kYPF) & 3], A.y + ro, c0, W);
-        if (pw_mask) gload_raw<PXL>(mpre[(U + kYPF) & 3], A.mask + ro, c0, W);
+        gload_raw<PXL>(ypre[(U + kYPF) & 3], A.y + ro, c0, W, al);
+        if (pw_mask) gload_raw<PXL>(mpre[(U + kYPF) & 3], A.mask + ro, c0, W, al);
       }
       {   // row t arrives: publish it in the ring (zeros below the image); fetch row t + 4
         float xv[PXL];
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) xv[k] = (t < H && c0 + (k & ~3) < W) ? xpre[U][k] : 0.f;
+        for (int k = 0; k < PXL; ++k) xv[k] = (t < H && c0 + k < W) ? xpre[U][k] : 0.f;
         prow_store<PXL>(ring_row(t), lane, xv);
-        gload_raw<PXL>(xpre[U], xin + (size_t)min(t + kXPF, H - 1) * W, c0, W);
+        gload_raw<PXL>(xpre[U], xin + (size_t)min(t + kXPF, H - 1) * W, c0, W, al);
       }
       if constexpr (CHAIN) {   // dual state row t - E - 1 of the previous link -> stage 1's hand-off slot P (read next tick)
         float* hb = lds + L::o_hand0 + P * 4 * BW;
@@ -313,7 +365,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
         const int rs = t + 2 - E - 1;
 #pragma unroll
         for (int f = 0; f < nsf; ++f)
-          gload_row<PXL>(spre[P][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H);
+          gload_row<PXL>(spre[P][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H, al);
       }
       if constexpr (KT > 0) {
       const int i = t + 1 - D + (KT - 1);       // blur input row (<= t-1: published in an earlier tick)
@@ -344,7 +396,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
           float acc = uv[0] * hxn[k];
 #pragma unroll
           for (int a = 1; a < KT; ++a) acc = fmaf(uv[a], hxw[kRing4 ? ((U - a) & 3) : a - 1][k], acc);
-          R[k] = (rowok && c0 + (k & ~3) < W) ? acc - ypre[U & 3][k] : 0.f;
+          R[k] = (rowok && c0 + k < W) ? acc - ypre[U & 3][k] : 0.f;
         }
         if (A.f_out) {
 #pragma unroll
@@ -394,7 +446,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
 #pragma unroll
           for (int k = 0; k < PXL; ++k) {
             float g = 0.f;
-            if (rowok && c0 + (k & ~3) < W) {
+            if (rowok && c0 + k < W) {
               if (pw_id) g = A.sigma_f * (xi[k] - ypre[U & 3][k]);
               else g = A.sigma_f * mpre[U & 3][k] * fmaf(mpre[U & 3][k], xi[k], -ypre[U & 3][k]);
             }
@@ -420,7 +472,11 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     const int k1 = 2 * wave - 1, k2 = 2 * wave;
     const float gam = A.tv.gamma, cstep = A.tv.c;
     const float beta1 = A.tv.betas[k1 - 1], beta2 = SINGLE ? 0.f : A.tv.betas[k2 - 1];
-    const float cr_last = (c0 + PXL - 1 == W - 1) ? 0.f : cstep;     // no horizontal difference across column W-1
+    PipeCr<PXL / 2> crc;                                              // see PipeCr: AL kernels need W % PXL == 0 (host check), the others take any W
+    crc.cstep = cstep;
+    crc.cr_last = (c0 + PXL - 1 == W - 1) ? 0.f : cstep;
+#pragma unroll
+    for (int i = 0; i < PXL / 2; ++i) crc.ncrv[i] = v2f{c0 + 2 * i == W - 1 ? 0.f : -cstep, c0 + 2 * i + 1 == W - 1 ? 0.f : -cstep};
     float* const hout = lds + L::o_hand + (wave - 1) * 8 * BW;       // this wave's hand-off [2][4][BW] ([2][2][BW] for the last one if CHAIN)
     const bool from_state = CHAIN && wave == 1 && A.tv_in != nullptr;
     constexpr bool warm = WARM;
@@ -467,19 +523,16 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
         if (sout && brow >= 0 && brow < H) {             // ... and the dual state of row brow for the next link / iteration
 #pragma unroll
           for (int g = 0; g < NP / 2; ++g) {
-            if (c0 + 4 * g < W) {
-              float* d = sout + (size_t)brow * W + c0 + 4 * g;
-              const float4 vp = make_float4(out.p[2 * g].x, out.p[2 * g].y, out.p[2 * g + 1].x, out.p[2 * g + 1].y);
-              const float4 vq = make_float4(out.q[2 * g].x, out.q[2 * g].y, out.q[2 * g + 1].x, out.q[2 * g + 1].y);
-              if (warm) {
-                *reinterpret_cast<float4*>(d) = vp;
-                *reinterpret_cast<float4*>(d + img) = vq;
-              } else {
-                *reinterpret_cast<float4*>(d) = make_float4(out.rr[2 * g].x, out.rr[2 * g].y, out.rr[2 * g + 1].x, out.rr[2 * g + 1].y);
-                *reinterpret_cast<float4*>(d + img) = make_float4(out.ss[2 * g].x, out.ss[2 * g].y, out.ss[2 * g + 1].x, out.ss[2 * g + 1].y);
-                *reinterpret_cast<float4*>(d + 2 * img) = vp;
-                *reinterpret_cast<float4*>(d + 3 * img) = vq;
-              }
+            float* d = sout + (size_t)brow * W;
+            const int cg = c0 + 4 * g;
+            if (warm) {
+              gstore4(d, cg, st_lo, st_hi, al, out.p[2 * g].x, out.p[2 * g].y, out.p[2 * g + 1].x, out.p[2 * g + 1].y);
+              gstore4(d + img, cg, st_lo, st_hi, al, out.q[2 * g].x, out.q[2 * g].y, out.q[2 * g + 1].x, out.q[2 * g + 1].y);
+            } else {
+              gstore4(d, cg, st_lo, st_hi, al, out.rr[2 * g].x, out.rr[2 * g].y, out.rr[2 * g + 1].x, out.rr[2 * g + 1].y);
+              gstore4(d + img, cg, st_lo, st_hi, al, out.ss[2 * g].x, out.ss[2 * g].y, out.ss[2 * g + 1].x, out.ss[2 * g + 1].y);
+              gstore4(d + 2 * img, cg, st_lo, st_hi, al, out.p[2 * g].x, out.p[2 * g].y, out.p[2 * g + 1].x, out.p[2 * g + 1].y);
+              gstore4(d + 3 * img, cg, st_lo, st_hi, al, out.q[2 * g].x, out.q[2 * g].y, out.q[2 * g + 1].x, out.q[2 * g + 1].y);
             }
           }
         }
@@ -491,7 +544,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       if constexpr (!SINGLE) {   // stage k2 on row a2: inputs are this wave's stage k1, one tick (row a2) and two ticks (row a2-1) old
         const float cdown = ((unsigned)(a2 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
         DualRow<NP> out;
-        pipe_stage<NP>(xk[P], o1[P ^ 1].rr, o1[P ^ 1].ss, o1[P], sol2, gam, cdown, cstep, cr_last, beta2, out);
+        pipe_stage<NP, AL>(xk[P], o1[P ^ 1].rr, o1[P ^ 1].ss, o1[P], sol2, gam, cdown, crc, beta2, out);
         emit(out, P, a2 - 1);
       }
       {   // stage k1 on row a1: inputs from the previous wave's hand-off (row a1) and the one read a tick earlier (row a1-1)
@@ -511,8 +564,8 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
         }
         pairs_load<NP>(xk[P], ring_row(a1), lane);      // read two ticks ago as row a1 = this tick's a2: consumed above
         const float cdown = ((unsigned)(a1 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
-        if constexpr (FIRST) pipe_stage_first<NP>(xk[P], sol1, cdown, cstep, cr_last, beta1, o1[P]);
-        else pipe_stage<NP>(xk[P], inb[P].rr, inb[P].ss, inb[P ^ 1], sol1, gam, cdown, cstep, cr_last, beta1, o1[P]);
+        if constexpr (FIRST) pipe_stage_first<NP, AL>(xk[P], sol1, cdown, crc, beta1, o1[P]);
+        else pipe_stage<NP, AL>(xk[P], inb[P].rr, inb[P].ss, inb[P ^ 1], sol1, gam, cdown, crc, beta1, o1[P]);
         if constexpr (SINGLE) emit(o1[P], P, a1 - 1);
       }
       PIPE_TICK_SYNC();
@@ -582,7 +635,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int r = u - D;
-        gload_raw<PXL>(exq[u], A.extra + (size_t)chain * img + (size_t)min(max(r, 0), H - 1) * W, c0, W);
+        gload_raw<PXL>(exq[u], A.extra + (size_t)chain * img + (size_t)min(max(r, 0), H - 1) * W, c0, W, al);
       }
     }
     auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
@@ -592,7 +645,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       if (CHAIN && A.tv_state_only) { PIPE_TICK_SYNC(); return; }     // this link only advances the dual state
       if (A.extra) {
         const int r3 = o + 3;
-        gload_raw<PXL>(exq[(U + 3) & 3], A.extra + (size_t)chain * img + (size_t)min(max(r3, 0), H - 1) * W, c0, W);
+        gload_raw<PXL>(exq[(U + 3) & 3], A.extra + (size_t)chain * img + (size_t)min(max(r3, 0), H - 1) * W, c0, W, al);
       }
       float css[PXL], xo[PXL], gv[PXL], prox[PXL];
       prow_load<PXL>(crr[P], hin + (P ^ 1) * HSTR, lane);            // rr^K on row o (written last tick)
@@ -643,14 +696,17 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
         const size_t go = (size_t)o * W;
 #pragma unroll
         for (int g = 0; g < PXL / 4; ++g) {
-          if (c0 + 4 * g < W) {
+          if (c0 + 4 * g < st_hi && c0 + 4 * g + 3 >= st_lo) {      // the group touches this workgroup's interior
             float xi[4] = {0.f, 0.f, 0.f, 0.f}, ex[4] = {0.f, 0.f, 0.f, 0.f};
             if (A.noise_mode == LMC_NOISE_PHILOX) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) xi[q] = slr[(NI * PXL + 4 * g + q) * 64];
             } else if (A.noise_mode == LMC_NOISE_INJECTED) {
-              const float4 v = *reinterpret_cast<const float4*>(A.noise + (size_t)chain * img + go + c0 + 4 * g);
-              xi[0] = v.x; xi[1] = v.y; xi[2] = v.z; xi[3] = v.w;
+              const float* nrow = A.noise + (size_t)chain * img + go;
+              if (al) {
+                const float4 v = *reinterpret_cast<const float4*>(nrow + c0 + 4 * g);
+                xi[0] = v.x; xi[1] = v.y; xi[2] = v.z; xi[3] = v.w;
+              } else load4_dword_aligned(xi[0], xi[1], xi[2], xi[3], nrow, c0 + 4 * g, W);
             }
             if (A.extra) { ex[0] = exq[U][4 * g]; ex[1] = exq[U][4 * g + 1]; ex[2] = exq[U][4 * g + 2]; ex[3] = exq[U][4 * g + 3]; }
             float ov[4];
@@ -661,7 +717,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
               if (A.extra) gr = fmaf(A.extra_coef, x - ex[q], gr);
               ov[q] = fmaf(A.a, x, fmaf(-A.t, gr, fmaf(A.b, prox[4 * g + q], A.s * xi[q])));
             }
-            *reinterpret_cast<float4*>(xout + go + c0 + 4 * g) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            gstore4(xout + go, c0 + 4 * g, st_lo, st_hi, al, ov[0], ov[1], ov[2], ov[3]);
           }
         }
       }
@@ -679,9 +735,9 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
 template <int K, int PXL, int KT, bool CHAIN = false>
 static constexpr size_t pipe_lds_bytes() { return sizeof(float) * (size_t)PipeLds<K, PXL, CHAIN>::total; }
 
-template <int PXL, int KT, bool CHAIN, int K = 10, bool WARM = false>
+template <int PXL, int KT, bool CHAIN, int K = 10, bool WARM = false, bool AL = true>
 static hipError_t pipe_launch_one(const StepArgs& a, hipStream_t st) {
-  auto kern = myula_step_pipe_kernel<K, PXL, KT, CHAIN, WARM>;
+  auto kern = myula_step_pipe_kernel<K, PXL, KT, CHAIN, WARM, AL>;
   constexpr size_t lb = pipe_lds_bytes<K, PXL, KT, CHAIN>();
   static bool attr_set[64] = {};        // per device: the attribute belongs to the function's code object on that device
   int dev = 0;
@@ -692,13 +748,33 @@ static hipError_t pipe_launch_one(const StepArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.C), dim3(64 * ((K + 1) / 2 + 3)), lb, st, a);
+  const int BWk = 64 * PXL, U = BWk - 2 * pipe_halo(K, KT, PXL);
+  const int nstrips = a.W <= BWk ? 1 : (a.W + U - 1) / U;       // wider than one wave: column strips with recomputed halos
+  hipLaunchKernelGGL(kern, dim3(a.C, nstrips), dim3(64 * ((K + 1) / 2 + 3)), lb, st, a);
   return hipGetLastError();
 }
 
 // one launch with K dual iterations: blur taps 5 / 7 / none (KT), 8 pixels per lane above 256 columns, else 4
+// rows not 16-byte aligned (W % 4 != 0): the pixel-by-pixel instantiations, K = 10 only (see pipe_links)
+template <int K, bool CHAIN>
+static hipError_t pipe_dispatch_unaligned(const StepArgs& a, int KT, hipStream_t st) {
+  if (a.W > 256) {
+    if (KT == 5) return pipe_launch_one<8, 5, CHAIN, K, false, false>(a, st);
+    if (KT == 7) return pipe_launch_one<8, 7, CHAIN, K, false, false>(a, st);
+    return pipe_launch_one<8, 0, CHAIN, K, false, false>(a, st);
+  }
+  if (KT == 5) return pipe_launch_one<4, 5, CHAIN, K, false, false>(a, st);
+  if (KT == 7) return pipe_launch_one<4, 7, CHAIN, K, false, false>(a, st);
+  return pipe_launch_one<4, 0, CHAIN, K, false, false>(a, st);
+}
+
 template <int K, bool CHAIN, bool WARM = false>
 static hipError_t pipe_dispatch_k(const StepArgs& a, int KT, hipStream_t st) {
+  const bool lastlane = (a.W & (a.W > 256 ? 7 : 3)) == 0;       // the last image column is the last pixel of a lane, rows are 16-byte aligned
+  if constexpr (K == 10 && !WARM) {
+    if (!lastlane) return pipe_dispatch_unaligned<K, CHAIN>(a, KT, st);
+  }
+  if (!lastlane) return hipErrorInvalidConfiguration;
   if (a.W > 256) {
     if (KT == 5) return pipe_launch_one<8, 5, CHAIN, K, WARM>(a, st);
     if (KT == 7) return pipe_launch_one<8, 7, CHAIN, K, WARM>(a, st);

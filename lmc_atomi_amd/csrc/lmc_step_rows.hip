@@ -43,20 +43,33 @@ __device__ __forceinline__ void rows_load(float (&dst)[PXL], const float* __rest
 
 // Unconditional load without the zero fill, for values masked where they are used (lanes past the row read its start; callers pass
 // a clamped, valid row): no exec-mask branch, and nothing touches the value before its use, so the prefetch stays in flight.
-template <int PXL>
+// AL = false: rows that do not start on 16-byte boundaries (W % 4 != 0): dword-aligned 16-byte accesses (lmc_device.h), masks per pixel.
+template <int PXL, bool AL = true>
 __device__ __forceinline__ void rows_load_raw(float (&dst)[PXL], const float* __restrict__ row, int c0, int W) {
+  if constexpr (AL) {
 #pragma unroll
-  for (int g = 0; g < PXL / 4; ++g) {
-    const float4 v = *reinterpret_cast<const float4*>(row + (c0 + 4 * g < W ? c0 + 4 * g : 0));
-    dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
+    for (int g = 0; g < PXL / 4; ++g) {
+      const float4 v = *reinterpret_cast<const float4*>(row + (c0 + 4 * g < W ? c0 + 4 * g : 0));
+      dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < PXL / 4; ++g) load4_dword_aligned(dst[4 * g], dst[4 * g + 1], dst[4 * g + 2], dst[4 * g + 3], row, c0 + 4 * g, W);
   }
+}
+template <bool AL>
+__device__ __forceinline__ void rows_load4(float (&dst)[4], const float* __restrict__ row, int c, int W) {
+  if constexpr (AL) {
+    const float4 v = *reinterpret_cast<const float4*>(row + c);
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+  } else load4_dword_aligned(dst[0], dst[1], dst[2], dst[3], row, c, W);
 }
 
 // ULO >= 0: UNIFORM-BOX form (the reference's only blurs: ones(k, k) / k^2, prox_lmc_deconv.py:55-69).  The centred taps are c_u on [ULO, UHI] and zero
 // elsewhere (same window for rows and columns), so every 1-D pass is a sliding window sum: 2 operations per pixel instead of KT (horizontal: the
 // first pixel of a lane directly, the next ones by +new -old; vertical: a running sum over a ring of the horizontally filtered rows, re-formed
 // directly every 8th row so that rounding cannot drift).  The scale c_u^2 c_v^2 sigma_f is applied once.  Same update to rounding (tests).
-template <int PXL, int KT, bool DOT = false, int ULO = -1, int UHI = -1>
+template <int PXL, int KT, bool DOT = false, int ULO = -1, int UHI = -1, bool AL = true>
 __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step_rows_kernel(const StepArgs P, const int band_rows, const int nbands) {
   using Gm = RowsGeom<PXL, KT>;
   constexpr int HW = Gm::HW, LAG = Gm::LAG, PF = Gm::PF;
@@ -68,11 +81,19 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   if (P.run_count && *P.run_count <= P.run_index) return;   // Chebyshev iteration the solve does not need (uniform, one scalar load)
   const int lane = threadIdx.x & 63;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (gw >= P.C * nbands) return;                       // whole waves leave; nothing below synchronises
-  const int chain = gw / nbands, band = gw - chain * nbands;
   const int H = P.H, W = P.W;
+  // Column strips (W > 64 PXL): a wave covers the columns [strip U - HALO, strip U - HALO + 64 PXL) of its band and writes the interior
+  // [strip U, (strip + 1) U); the gradient of a pixel needs x within KT - 1 columns, so the HALO columns either side are recomputed, not exchanged.
+  constexpr int HALO = 8, USTRIP = 64 * PXL - 2 * HALO;        // strips only ever run 8 pixels per lane (W > 512)
+  static_assert(HALO >= KT - 1, "strip halo");
+  const int nstrips = W <= 64 * PXL ? 1 : (W + USTRIP - 1) / USTRIP;
+  if (gw >= P.C * nbands * nstrips) return;             // whole waves leave; nothing below synchronises
+  const int chain = gw / (nbands * nstrips), bs = gw - chain * (nbands * nstrips);
+  const int strip = bs / nbands, band = bs - strip * nbands;
   const int r0 = band * band_rows, r1 = min(r0 + band_rows, H);
-  const int c0 = lane * PXL;
+  const int st_lo = nstrips > 1 ? strip * USTRIP : 0, st_hi = nstrips > 1 ? min(W, st_lo + USTRIP) : W;
+  const int c0 = (strip ? st_lo - HALO : 0) + lane * PXL;        // GLOBAL column of the lane's first pixel
+  auto colok = [&](int k) { return AL ? c0 + (k & ~3) < W : c0 + k < W; };
   const size_t img = (size_t)H * W;
   const float* __restrict__ xin = P.x_in + (size_t)chain * img;
   float* __restrict__ xout = P.x_out + (size_t)chain * img;
@@ -107,7 +128,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   static_for<0, PF>([&](auto pp) {
     constexpr int p = decltype(pp)::value;
     const int i = i_first + p;
-    rows_load_raw<PXL>(xr[(8 - LAG + p) & 7], xin + (size_t)min(max(i, 0), H - 1) * W, c0, W);
+    rows_load_raw<PXL, AL>(xr[(8 - LAG + p) & 7], xin + (size_t)min(max(i, 0), H - 1) * W, c0, W);
   });
 
   // Vector-memory loads return in order, so the load a step consumes must be older than the x rows still in flight for later steps:
@@ -117,7 +138,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   static_for<0, kYD>([&](auto dd) {   // observation rows of the first kYD steps (residual rows i_first - HW + d, slot (J & 3))
     constexpr int d = decltype(dd)::value;
     const int r = i_first + d - HW;
-    rows_load_raw<PXL>(yq[(8 - LAG + d) & 3], P.y + (size_t)min(max(r, 0), H - 1) * W, c0, W);
+    rows_load_raw<PXL, AL>(yq[(8 - LAG + d) & 3], P.y + (size_t)min(max(r, 0), H - 1) * W, c0, W);
   });
 
   double dacc = 0.0;       // sum x_in * x_out over this wave's band (P.dot_out: the p.Ap of CG); dot_mode 1: sum (x_out - x_in)^2
@@ -129,14 +150,14 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
     constexpr int J = decltype(jj)::value;
     const int i = base + J;
       // (0) the observation row of the step after next
-      rows_load_raw<PXL>(yq[(J + kYD) & 3], P.y + (size_t)min(max(i + kYD - HW, 0), H - 1) * W, c0, W);
+      rows_load_raw<PXL, AL>(yq[(J + kYD) & 3], P.y + (size_t)min(max(i + kYD - HW, 0), H - 1) * W, c0, W);
       // (1) horizontal blur of x row i
       float hx[PXL];
       {
         float e[PXL + 2 * HW], xm[PXL];
         const bool rowin = i >= 0 && i < H;           // the ring holds raw loads: rows / columns outside the image are zeros HERE
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) xm[k] = (rowin && c0 + (k & ~3) < W) ? xr[J][k] : 0.f;
+        for (int k = 0; k < PXL; ++k) xm[k] = (rowin && colok(k)) ? xr[J][k] : 0.f;
 #pragma unroll
         for (int m = 0; m < HW; ++m) e[m] = dpp_left0(xm[PXL - HW + m]);
 #pragma unroll
@@ -179,7 +200,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
         }
         const bool rowok = r >= 0 && r < H && r >= r0 - HW;      // rows before the band's first residual row: partial windows, kept out
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) R[k] = (rowok && c0 + (k & ~3) < W) ? fmaf(cbox, Vs[k], -yq[J & 3][k]) : 0.f;
+        for (int k = 0; k < PXL; ++k) R[k] = (rowok && colok(k)) ? fmaf(cbox, Vs[k], -yq[J & 3][k]) : 0.f;
       } else {
       // (2) scatter into the residual accumulators of rows i-HW .. i+HW (the last one starts here)
       static_for<0, KT>([&](auto aa) {
@@ -193,7 +214,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
       {
         const bool rowok = r >= 0 && r < H;
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) R[k] = (rowok && c0 + (k & ~3) < W) ? A[sr][k] - yq[J & 3][k] : 0.f;
+        for (int k = 0; k < PXL; ++k) R[k] = (rowok && colok(k)) ? A[sr][k] - yq[J & 3][k] : 0.f;
       }
       }
       // (4) horizontal adjoint of the residual row
@@ -272,26 +293,17 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
         const size_t go = (size_t)o * W;
 #pragma unroll
         for (int g = 0; g < PXL / 4; ++g) {
-          if (c0 + 4 * g < W) {
+          if (c0 + 4 * g < st_hi && c0 + 4 * g + 3 >= st_lo) {       // the group touches this wave's interior (AL: inside or outside as a whole)
             float xi[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               if constexpr (kNzLds) xi[q] = nzw[(jq * PXL + 4 * g + q) * 64];
               else xi[q] = nz[4 * g + q][jq];
             }
-            if (P.noise_mode == LMC_NOISE_INJECTED) {
-              const float4 v = *reinterpret_cast<const float4*>(P.noise + (size_t)chain * img + go + c0 + 4 * g);
-              xi[0] = v.x; xi[1] = v.y; xi[2] = v.z; xi[3] = v.w;
-            }
+            if (P.noise_mode == LMC_NOISE_INJECTED) rows_load4<AL>(xi, P.noise + (size_t)chain * img + go, c0 + 4 * g, W);
             float pe[4] = {0.f, 0.f, 0.f, 0.f}, ex[4] = {0.f, 0.f, 0.f, 0.f};
-            if (P.prox_ext) {
-              const float4 v = *reinterpret_cast<const float4*>(P.prox_ext + (size_t)chain * img + go + c0 + 4 * g);
-              pe[0] = v.x; pe[1] = v.y; pe[2] = v.z; pe[3] = v.w;
-            }
-            if (P.extra) {
-              const float4 v = *reinterpret_cast<const float4*>(P.extra + (size_t)chain * img + go + c0 + 4 * g);
-              ex[0] = v.x; ex[1] = v.y; ex[2] = v.z; ex[3] = v.w;
-            }
+            if (P.prox_ext) rows_load4<AL>(pe, P.prox_ext + (size_t)chain * img + go, c0 + 4 * g, W);
+            if (P.extra) rows_load4<AL>(ex, P.extra + (size_t)chain * img + go, c0 + 4 * g, W);
             float ov[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -304,6 +316,8 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
               if (P.prox_ext) px = pe[q];
               ov[q] = fmaf(P.a, x, fmaf(-P.t, gr, fmaf(P.b, px, P.s * xi[q])));
               if constexpr (DOT) {
+                const bool mine = AL || (c0 + 4 * g + q >= st_lo && c0 + 4 * g + q < st_hi);
+                if (!mine) continue;
                 if (P.dot_mode == 0) dacc = fma((double)x, (double)ov[q], dacc);
                 else {
                   const double d = (double)ov[q] - (double)x;
@@ -312,14 +326,15 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
                 }
               }
             }
-            *reinterpret_cast<float4*>(xout + go + c0 + 4 * g) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            if constexpr (AL) *reinterpret_cast<float4*>(xout + go + c0 + 4 * g) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            else store4_dword_aligned(xout + go, c0 + 4 * g, st_lo, st_hi, ov[0], ov[1], ov[2], ov[3]);
           }
         }
       }
       // (7) fetch x row i + PF into the slot row i + PF - 8 has just left (its last use was step (6) above at the latest)
       {
         const int ip = i + PF;
-        rows_load_raw<PXL>(xr[(J + PF) & 7], xin + (size_t)min(max(ip, 0), H - 1) * W, c0, W);
+        rows_load_raw<PXL, AL>(xr[(J + PF) & 7], xin + (size_t)min(max(ip, 0), H - 1) * W, c0, W);
       }
   };
   const int r1r = (r1 + 7) & ~7;
@@ -377,7 +392,8 @@ bool rows_supported(const StepArgs& a) {
   if (a.data_kind != LMC_DATA_BLUR || a.ncvx_kind != LMC_NCVX_NONE) return false;
   if (a.prior_kind != LMC_PRIOR_NONE && a.prior_kind != LMC_PRIOR_L2 && a.prior_kind != LMC_PRIOR_L1) return false;
   if (a.tv_in || a.tv_out) return false;
-  if ((a.W & 3) || a.W > 512 || a.W < 4 || a.H < 1) return false;
+  // any width: rows that are not 16-byte aligned (W % 4 != 0) go pixel by pixel, images wider than one wave (512 columns) as column strips
+  if (a.W < 4 || a.W > 16384 || a.H < 1) return false;
   float uc[kMaxBlur], vc[kMaxBlur];
   const int KT = centred_blur_taps(a, uc, vc);
   if (KT == 0) return false;
@@ -401,10 +417,18 @@ hipError_t launch_step_rows(StepArgs a, hipStream_t st) {
   }
   band = (band + 7) & ~7;
   const int nbands = (a.H + band - 1) / band;
-  const long long waves = (long long)a.C * nbands;
+  const bool al = (a.W & 3) == 0;
+  const int pxl = (a.W <= 256 && al) ? 4 : 8;                        // the pixel-by-pixel instantiations are 8 per lane only
+  const int ustrip = 64 * pxl - 16;
+  const int nstrips = a.W <= 64 * pxl ? 1 : (a.W + ustrip - 1) / ustrip;     // as in the kernel
+  const long long waves = (long long)a.C * nbands * nstrips;
+  if (waves > (1ll << 31) - 8) return hipErrorInvalidConfiguration;
   const int nblk = (int)((waves + 3) / 4);
   if (a.dot_out) {        // CG operator apply with the p.Ap reduction fused (lmc_capi.hip: cg_solve_fused)
-    if (a.W <= 256) {
+    if (!al) {
+      if (KT == 5) hipLaunchKernelGGL((myula_step_rows_kernel<8, 5, true, -1, -1, false>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+      else hipLaunchKernelGGL((myula_step_rows_kernel<8, 7, true, -1, -1, false>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+    } else if (a.W <= 256) {
       if (KT == 5) hipLaunchKernelGGL((myula_step_rows_kernel<4, 5, true>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
       else hipLaunchKernelGGL((myula_step_rows_kernel<4, 7, true>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
     } else {
@@ -428,18 +452,23 @@ hipError_t launch_step_rows(StepArgs a, hipStream_t st) {
     int l2, h2;
     if (!(window(uc, lo, hi) && window(vc, l2, h2) && l2 == lo && h2 == hi)) lo = hi = -1;
   }
-#define LMC_ROWS_UNI_LAUNCH(PX, KTT, LO, HI)                                                                                   \
+#define LMC_ROWS_UNI_LAUNCH(PX, KTT, LO, HI, ...)                                                                              \
   if (KT == KTT && lo == LO && hi == HI) {                                                                                   \
-    hipLaunchKernelGGL((myula_step_rows_kernel<PX, KTT, false, LO, HI>), dim3(nblk), dim3(256), 0, st, a, band, nbands);      \
+    hipLaunchKernelGGL((myula_step_rows_kernel<PX, KTT, false, LO, HI, ##__VA_ARGS__>), dim3(nblk), dim3(256), 0, st, a, band, nbands); \
     return hipGetLastError();                                                                                                \
   }
-  if (a.W <= 256) {
+  if (!al) {
+    LMC_ROWS_UNI_LAUNCH(8, 5, 0, 4, false) LMC_ROWS_UNI_LAUNCH(8, 7, 0, 6, false) LMC_ROWS_UNI_LAUNCH(8, 7, 0, 5, false)
+  } else if (a.W <= 256) {
     LMC_ROWS_UNI_LAUNCH(4, 5, 0, 4) LMC_ROWS_UNI_LAUNCH(4, 7, 0, 6) LMC_ROWS_UNI_LAUNCH(4, 7, 0, 5)
   } else {
     LMC_ROWS_UNI_LAUNCH(8, 5, 0, 4) LMC_ROWS_UNI_LAUNCH(8, 7, 0, 6) LMC_ROWS_UNI_LAUNCH(8, 7, 0, 5)
   }
 #undef LMC_ROWS_UNI_LAUNCH
-  if (a.W <= 256) {
+  if (!al) {
+    if (KT == 5) hipLaunchKernelGGL((myula_step_rows_kernel<8, 5, false, -1, -1, false>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+    else hipLaunchKernelGGL((myula_step_rows_kernel<8, 7, false, -1, -1, false>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+  } else if (a.W <= 256) {
     if (KT == 5) hipLaunchKernelGGL((myula_step_rows_kernel<4, 5>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
     else hipLaunchKernelGGL((myula_step_rows_kernel<4, 7>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
   } else {

@@ -265,8 +265,9 @@ def test_split_and_tile_variants_agree(la):
 
 
 def test_wide_images_use_tiled_kernels(la, variant):
-    """W > 512 (e.g. the reference's 667 x 877 einstein image, prox_lmc_deconv.py:46): closed-form priors run on the
-    'point' kernel, TV on the LDS-tiled kernel; both against the oracle with injected noise."""
+    """W > 512 and W % 4 != 0 (e.g. the reference's 667 x 877 einstein image, prox_lmc_deconv.py:46): closed-form priors run on the
+    row-streaming kernel and TV K = 10 on the pipeline (column strips, dword-aligned accesses; tests/test_gpu_wide.py); the 'point' kernel and
+    the LDS-tiled kernel (other dual-iteration counts) stay as the general fallbacks; all against the oracle with injected noise."""
     if variant != "auto":
         pytest.skip("dispatch test")
     rng = np.random.default_rng(9)
@@ -274,10 +275,12 @@ def test_wide_images_use_tiled_kernels(la, variant):
     img, h, y = synth(*shape, seed=5)
     noise = rng.standard_normal((2, 2) + shape)
     x0 = img[None] + rng.normal(0, 10, (2,) + shape)
-    for pg, kern, prior in [(la.L1(sigma=0.3), "point", {"kind": "l1", "sigma": 0.3, "t": 0.5625}),
-                            (la.TV(shape, sigma=0.3, niter=4), "tile", {"kind": "tv", "sigma": 0.3, "niter": 4, "t": 0.5625})]:
+    for pg, kern, var, prior in [(la.L1(sigma=0.3), "rows", None, {"kind": "l1", "sigma": 0.3, "t": 0.5625}),
+                                 (la.L1(sigma=0.3), "point", "point", {"kind": "l1", "sigma": 0.3, "t": 0.5625}),
+                                 (la.TV(shape, sigma=0.3, niter=10), "pipe", None, {"kind": "tv", "sigma": 0.3, "niter": 10, "t": 0.5625}),
+                                 (la.TV(shape, sigma=0.3, niter=4), "tile", None, {"kind": "tv", "sigma": 0.3, "niter": 4, "t": 0.5625})]:
         pf = la.L2(Op=la.Convolve2D(shape, h), b=y, sigma=1 / 0.5625)
-        smp = la.MYULASampler(pf, pg, shape, n_chains=2, tau=0.1125, gamma=0.5625, noise="injected")
+        smp = la.MYULASampler(pf, pg, shape, n_chains=2, tau=0.1125, gamma=0.5625, noise="injected", variant=var)
         smp.set_state(x0)
         smp.step(2, noise=noise)
         assert kern in smp.kernel_name, smp.kernel_name

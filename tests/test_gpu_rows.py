@@ -90,11 +90,13 @@ def test_rows_kernel_philox_matches_tile_and_is_the_default(la):
 
 
 def test_rows_kernel_not_used_outside_its_domain(la):
-    """W % 4 != 0, non-separable or off-centre-beyond-7 taps, TV prior: the dispatcher must pick another kernel."""
+    """Non-separable taps (or a TV prior): the dispatcher must pick another kernel.  W % 4 != 0 is INSIDE the domain since round 2
+    (dword-aligned 16-byte accesses; tests/test_gpu_wide.py)."""
     rng = np.random.default_rng(5)
     shape = (24, 30)
     img, h, off, y = problem(shape, 5, rng)
-    pf = la.L2(Op=la.Convolve2D(shape, h, offset=off), b=y, sigma=1.0)
+    hn = rng.uniform(0.5, 1.5, (5, 5)); hn /= hn.sum()              # rank > 1
+    pf = la.L2(Op=la.Convolve2D(shape, hn, offset=off), b=y, sigma=1.0)
     la.set_step_variant("rows")
     smp = la.MYULASampler(pf, la.L2(sigma=0.05), shape, n_chains=1, tau=0.1, gamma=0.5)
     with pytest.raises(la.LMCError):
@@ -104,4 +106,9 @@ def test_rows_kernel_not_used_outside_its_domain(la):
     smp = la.MYULASampler(pf, la.L2(sigma=0.05), shape, n_chains=1, tau=0.1, gamma=0.5)
     smp.step(1)
     assert smp.kernel_name != "myula_step_rows_kernel"
+    smp.close()
+    pf = la.L2(Op=la.Convolve2D(shape, h, offset=off), b=y, sigma=1.0)
+    smp = la.MYULASampler(pf, la.L2(sigma=0.05), shape, n_chains=1, tau=0.1, gamma=0.5)
+    smp.step(1)
+    assert smp.kernel_name == "myula_step_rows_kernel"
     smp.close()
