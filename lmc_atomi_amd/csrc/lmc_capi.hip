@@ -345,8 +345,13 @@ hipError_t launch_step(const lmc::StepArgs& A_in, int variant, hipStream_t st, c
 // max|p_k| <= 2 c^k, c = (sqrt(kappa) - 1) / (sqrt(kappa) + 1): the iteration count for the reference's stopping rule |r| <= tol |b|
 // (scipy lsqr btol, algs.py:250) is known in advance -- no convergence test, no flags, no host synchronisation.
 // Returns hipErrorInvalidConfiguration when the row-streaming kernel does not cover the problem (caller falls back to CG).
+// pb (optional): two scratch arrays and the array that receives the solution, all [C][H][W] and distinct from u / tmp / rhs.  With them, and
+// where lmc_cheb_pair.hip covers the problem, the iterations after the first run TWO per launch (20 instead of 32 B per pixel); the solution
+// then arrives in pb->out, u (the starting guess) is used as scratch, and *result says which of the two holds it.
+struct ChebPairBufs { float* b1; float* b2; float* out; };
 static hipError_t chebyshev_solve(const Problem& q, float ts, float* u, const float* rhs, float* tmp, double* scal, int64_t C, int niter_cap,
-                                  float tol, const float* zero_y, hipStream_t st) {
+                                  float tol, const float* zero_y, hipStream_t st, const ChebPairBufs* pb = nullptr, float** result = nullptr) {
+  if (result) *result = u;
   lmc::StepArgs A;
   std::memset(&A, 0, sizeof A);
   A.H = q.H; A.W = q.W; A.C = (int)C;
@@ -376,61 +381,134 @@ static hipError_t chebyshev_solve(const Problem& q, float ts, float* u, const fl
   // number of launches needed (even, <= the a-priori count), and the launches beyond it return at their first instruction.
   // (the adaptive count is even; when rounding up would exceed the caller's cap the a-priori count runs as it is)
   const bool adaptive = env_k <= 0 && K > 2 && delta > 1e-12 * theta && ((K + 1) & ~1) <= niter_cap;
-  double* stat = scal;                                   // [2C]
-  int* count = reinterpret_cast<int*>(scal + 4 * C);     // the solver's flag word
   if (adaptive) {
     K = (K + 1) & ~1;
     hipError_t e = hipMemsetAsync(scal, 0, sizeof(double) * (4 * C + 1), st);
     if (e != hipSuccess) return e;
   }
-  float* cur = u;
-  float* oth = tmp;
-  double rho = delta > 0 ? delta / theta : 0.0;      // rho_0 = 1 / sigma_1
-  const double sigma1 = delta > 0 ? theta / delta : 0.0;
-  for (int k = 0; k < K; ++k) {
-    double alpha, beta;
-    if (k == 0 || !(delta > 1e-12 * theta)) { alpha = 1.0 / theta; beta = 0.0; }
-    else {
-      const double rho_new = 1.0 / (2.0 * sigma1 - rho);
-      alpha = 2.0 * rho_new / delta;
-      beta = rho_new * rho;
-      rho = rho_new;
+  // Chain chunks: the K launches of one chunk run back to back, so u_k, u_{k-1} and rhs of that chunk (3 arrays) are still in the 256 MB
+  // memory-side cache when the next launch reads them.  LMC_CHEB_CHUNK = chains per chunk (0 / unset: one chunk).
+  static const int64_t env_chunk = [] { const char* e = getenv("LMC_CHEB_CHUNK"); return e ? (int64_t)atoll(e) : 0; }();
+  const int64_t chunk = env_chunk > 0 && env_chunk < C ? env_chunk : C;
+  const size_t img = (size_t)q.H * q.W;
+  // LMC_CHEB_PAIR: 0 = single-iteration launches only, 2 = pairs wherever the kernel covers the problem (tests), default = where they pay;
+  // read per call so that a test can switch it
+  const char* pair_env = getenv("LMC_CHEB_PAIR");
+  const int pair_mode = pair_env ? atoi(pair_env) : 1;
+  const bool pair_on = pair_mode == 2 || (pair_mode == 1 && lmc::cheb_pair_pays(C, q.H));
+  if (pb && result && pair_on && chunk == C && K >= 3 && delta > 1e-12 * theta && lmc::cheb_pair_supported(q.H, q.W, q.taps)) {
+    // iteration 0 (with the residual statistics of the adaptive count): u -> tmp; then pairs p = 1 .. M of iterations 2p - 1, 2p
+    const int M = K / 2;                                       // K even (adaptive) or odd: 1 + 2M >= K iterations at most
+    const int n_it = 1 + 2 * M;
+    std::vector<double> al(n_it), be(n_it);
+    {
+      double rho = delta / theta;
+      const double sigma1 = theta / delta;
+      al[0] = 1.0 / theta; be[0] = 0.0;
+      for (int k = 1; k < n_it; ++k) {
+        const double rho_new = 1.0 / (2.0 * sigma1 - rho);
+        al[k] = 2.0 * rho_new / delta;
+        be[k] = rho_new * rho;
+        rho = rho_new;
+      }
     }
-    A.x_in = cur; A.x_out = oth;
-    A.a = (float)(1.0 - alpha + beta);
-    A.t = (float)(alpha * (double)ts / (double)q.sigma_f);
-    A.b = (float)alpha;
-    if (beta != 0.0) { A.noise_mode = LMC_NOISE_INJECTED; A.noise = oth; A.s = (float)(-beta); }   // oth holds u_{k-1} and receives u_{k+1}
-    else { A.noise_mode = LMC_NOISE_NONE; A.noise = zero_y; A.s = 0.f; }
-    A.dot_out = nullptr; A.dot_mode = 0; A.run_count = nullptr; A.run_index = 0;
-    if (adaptive) {
-      if (k == 0) { A.dot_out = stat; A.dot_mode = 1; }
-      else { A.run_count = count; A.run_index = k; }
-    }
+    double* stat = scal;
+    int* count = reinterpret_cast<int*>(scal + 4 * C);
+    A.x_in = u; A.x_out = tmp;
+    A.a = (float)(1.0 - al[0]); A.t = (float)(al[0] * (double)ts / (double)q.sigma_f); A.b = (float)al[0];
+    A.noise_mode = LMC_NOISE_NONE; A.noise = zero_y; A.s = 0.f;
+    A.dot_out = adaptive ? stat : nullptr; A.dot_mode = adaptive ? 1 : 0; A.run_count = nullptr; A.run_index = 0;
     hipError_t e = lmc::launch_step_rows(A, st);
     if (e != hipSuccess) return e;
-    if (adaptive && k == 0) {
+    if (adaptive) {
       const double sk = std::sqrt(lmax / lmin), c = (sk - 1.0) / (sk + 1.0);
       e = lmc::cheb_count(C, stat, 1.0 / ((double)A.b * (double)A.b), (double)tol, 1.0 / std::log(1.0 / c), K, count, st);
       if (e != hipSuccess) return e;
     }
-    float* t = cur; cur = oth; oth = t;
+    float* cur = tmp;
+    float* prv = u;
+    float* f1 = pb->b1;
+    float* f2 = pb->b2;
+    for (int p = 1; p <= M; ++p) {
+      const int k0 = 2 * p - 1, k1 = 2 * p;
+      lmc::ChebPairArgs P;
+      std::memset(&P, 0, sizeof P);
+      P.H = q.H; P.W = q.W; P.C = (int)C;
+      P.cur = cur; P.prv = prv; P.rhs = rhs; P.f1 = f1; P.f2 = f2; P.f2_last = pb->out;
+      P.a0 = (float)(1.0 - al[k0] + be[k0]); P.tg0 = (float)(al[k0] * (double)ts); P.b0 = (float)al[k0]; P.s0 = (float)(-be[k0]);
+      P.a1 = (float)(1.0 - al[k1] + be[k1]); P.tg1 = (float)(al[k1] * (double)ts); P.b1 = (float)al[k1]; P.s1 = (float)(-be[k1]);
+      P.run_count = adaptive ? count : nullptr;
+      P.run_index = p == 1 ? -1 : k0;           // the first pair always runs (the solution has to arrive in pb->out)
+      P.last_index = k1 + 1;                    // no later pair runs when *count <= 2p + 1
+      P.force_last = p == M;
+      e = lmc::launch_cheb_pair(P, q.taps, st);
+      if (e != hipSuccess) return e;
+      float* oc = cur; float* op = prv;
+      cur = f2; prv = f1; f1 = oc; f2 = op;
+    }
+    *result = pb->out;
+    return hipSuccess;
   }
-  if (cur != u) {
-    hipError_t e = hipMemcpyAsync(u, cur, sizeof(float) * (size_t)C * q.H * q.W, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return e;
+  int ci = 0;
+  for (int64_t c0 = 0; c0 < C; c0 += chunk, ++ci) {
+    const int64_t nc = C - c0 < chunk ? C - c0 : chunk;
+    if (ci >= 2 * C) return hipErrorInvalidConfiguration;
+    double* stat = scal + 2 * c0;                            // [2 nc] of the [2C] block
+    int* count = reinterpret_cast<int*>(scal + 2 * C) + ci;  // the solver's flag word of this chunk (the second [2C] block is free here)
+    A.C = (int)nc;
+    A.prox_ext = rhs + c0 * img;
+    float* cur = u + c0 * img;
+    float* oth = tmp + c0 * img;
+    double rho = delta > 0 ? delta / theta : 0.0;      // rho_0 = 1 / sigma_1
+    const double sigma1 = delta > 0 ? theta / delta : 0.0;
+    for (int k = 0; k < K; ++k) {
+      double alpha, beta;
+      if (k == 0 || !(delta > 1e-12 * theta)) { alpha = 1.0 / theta; beta = 0.0; }
+      else {
+        const double rho_new = 1.0 / (2.0 * sigma1 - rho);
+        alpha = 2.0 * rho_new / delta;
+        beta = rho_new * rho;
+        rho = rho_new;
+      }
+      A.x_in = cur; A.x_out = oth;
+      A.a = (float)(1.0 - alpha + beta);
+      A.t = (float)(alpha * (double)ts / (double)q.sigma_f);
+      A.b = (float)alpha;
+      if (beta != 0.0) { A.noise_mode = LMC_NOISE_INJECTED; A.noise = oth; A.s = (float)(-beta); }   // oth holds u_{k-1} and receives u_{k+1}
+      else { A.noise_mode = LMC_NOISE_NONE; A.noise = zero_y; A.s = 0.f; }
+      A.dot_out = nullptr; A.dot_mode = 0; A.run_count = nullptr; A.run_index = 0;
+      if (adaptive) {
+        if (k == 0) { A.dot_out = stat; A.dot_mode = 1; }
+        else { A.run_count = count; A.run_index = k; }
+      }
+      hipError_t e = lmc::launch_step_rows(A, st);
+      if (e != hipSuccess) return e;
+      if (adaptive && k == 0) {
+        const double sk = std::sqrt(lmax / lmin), c = (sk - 1.0) / (sk + 1.0);
+        e = lmc::cheb_count(nc, stat, 1.0 / ((double)A.b * (double)A.b), (double)tol, 1.0 / std::log(1.0 / c), K, count, st);
+        if (e != hipSuccess) return e;
+      }
+      float* t = cur; cur = oth; oth = t;
+    }
+    if (cur != u + c0 * img) {
+      hipError_t e = hipMemcpyAsync(u + c0 * img, cur, sizeof(float) * (size_t)nc * img, hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return e;
+    }
   }
   return hipSuccess;
 }
 
+// alt_out / result (optional, both or none): an extra [C][H][W] array the solution may arrive in instead of u (*result tells); u is then scratch.
 int cg_solve_fused(const Problem& q, float ts, float* u, const float* rhs, float* r, float* p, float* qq, double* scal,
-                   int64_t C, int niter, const float* zero_y, hipStream_t st) {
+                   int64_t C, int niter, const float* zero_y, hipStream_t st, float* alt_out = nullptr, float** result = nullptr) {
+  if (result) *result = u;
   const size_t img = (size_t)q.H * q.W;
   // LMC_IMPLICIT_SOLVER=cg keeps the conjugate-gradient path below (A/B runs); default: Chebyshev whenever a tolerance is set
   static const bool want_cheb = [] { const char* e = getenv("LMC_IMPLICIT_SOLVER"); return !(e && std::strcmp(e, "cg") == 0); }();
   const float cg_tol = tol_of(q);
   if (want_cheb && cg_tol > 0.f) {
-    hipError_t e = chebyshev_solve(q, ts, u, rhs, r, scal, C, niter, cg_tol, zero_y, st);
+    const ChebPairBufs pb{p, qq, alt_out};
+    hipError_t e = chebyshev_solve(q, ts, u, rhs, r, scal, C, niter, cg_tol, zero_y, st, alt_out && result ? &pb : nullptr, result);
     if (e == hipSuccess) return LMC_OK;
     if (e != hipErrorInvalidConfiguration) HIP_TRY(e);
   }
@@ -558,6 +636,7 @@ struct lmc_sampler {
   int gfirst = 0, cg_niter = 0, warm = 1;
   const float* z = nullptr;
   float* xhat = nullptr; float* ydual = nullptr; float* uw = nullptr; float* rhs = nullptr;
+  float* uw2 = nullptr;       // ULPDA: the other home of the implicit-step solution (two Chebyshev iterations per launch deliver it there)
   float* cr = nullptr; float* cp = nullptr; float* cq = nullptr; float* ctmp = nullptr; float* xi = nullptr;
   float* htb = nullptr; double* scal = nullptr; float* zero_y = nullptr;
   float* tvstate[2] = {nullptr, nullptr};   // dual-state ping-pong for chunked TV proxes (K > 12, ME-TV)
@@ -930,7 +1009,7 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
 void lmc_sampler_destroy(lmc_sampler* s) {
   if (!s) return;
   DeviceGuard dg(s->device);
-  for (float* b : {s->zero_y, s->xhat, s->ydual, s->uw, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra, s->pxbuf,
+  for (float* b : {s->zero_y, s->xhat, s->ydual, s->uw, s->uw2, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra, s->pxbuf,
                    s->mx, s->xp, s->mxp, s->tvwarm[0], s->tvwarm[1], s->rtmp})
     if (b) (void)hipFree(b);
   if (s->robj) (void)hipFree(s->robj);
@@ -1343,6 +1422,7 @@ static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, h
   // loads: the same) against 0.76 + 0.94 ms for the two flat passes (5.6 TB/s each) -- 8.0 ms per iteration either way.  Exact (test_gpu_ulpda.py).
   static const bool fuse_env = [] { const char* e = getenv("LMC_ULPDA_FUSE"); return e && atoi(e) != 0; }();
   const bool fuse_fd = fuse_env && !s->gfirst && s->x[1] && lmc::ulpda_finish_dual_supported(H, W);
+  bool used_pairs = false;
   for (int k = 0; k < n_iters; ++k) {
     float* x = s->x[s->cur];
     const float ts = s->tau * s->prob.sigma_f;
@@ -1362,7 +1442,9 @@ static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, h
     const float* u = s->rhs;
     if (s->prob.data_kind == LMC_DATA_BLUR) {
       if (!s->warm) HIP_TRY(hipMemsetAsync(s->uw, 0, sizeof(float) * per_iter, st));
-      { int rc = cg_solve_fused(s->prob, ts, s->uw, s->rhs, s->cr, s->cp, s->cq, s->scal, C, s->cg_niter, s->zero_y, st); if (rc) return rc; }
+      float* where = s->uw;
+      { int rc = cg_solve_fused(s->prob, ts, s->uw, s->rhs, s->cr, s->cp, s->cq, s->scal, C, s->cg_niter, s->zero_y, st, s->uw2, &where); if (rc) return rc; }
+      if (where != s->uw) { s->uw2 = s->uw; s->uw = where; used_pairs = true; }       // the pair launches deliver the solution in the other array
       u = s->uw;
     } else if (s->prob.data_kind != LMC_DATA_NONE) {
       HIP_TRY(lmc::ulpda_pointwise_prox(s->rhs, s->uw, s->prob.y, s->prob.mask, C, H, W, ts, s->prob.data_kind, st));
@@ -1396,7 +1478,7 @@ static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, h
     }
     ++s->iteration;
   }
-  s->kernel_name = "ulpda (multi-kernel)";
+  s->kernel_name = used_pairs ? "ulpda (multi-kernel, chebyshev pairs)" : "ulpda (multi-kernel)";
   return LMC_OK;
 }
 
@@ -1444,6 +1526,7 @@ int lmc_ulpda_create(const lmc_ulpda_config* cfg, lmc_sampler** out) {
   if (s->noise_mode == LMC_NOISE_PHILOX) alloc(&s->xi, n);
   if (s->prob.data_kind == LMC_DATA_BLUR) {
     alloc(&s->cr, n); alloc(&s->cp, n); alloc(&s->cq, n); alloc(&s->ctmp, n); alloc(&s->htb, img); alloc(&s->zero_y, img);
+    if (lmc::cheb_pair_supported(s->prob.H, s->prob.W, s->prob.taps)) alloc(&s->uw2, n);
     if (e == hipSuccess) e = hipMalloc(&s->scal, sizeof(double) * (4 * (size_t)s->C + 1));
     if (e == hipSuccess) e = lmc::launch_blur(s->prob.y, s->htb, 1, s->prob.H, s->prob.W, s->prob.taps, 1, nullptr);   // H^T b
     if (e == hipSuccess) e = hipDeviceSynchronize();

@@ -101,6 +101,27 @@ hipError_t cg_dir(float* p, const float* r, int64_t C, size_t img, double* rs, c
 hipError_t cheb_count(int64_t C, const double* stat, double inv_alpha2, double tol, double inv_log_inv_c, int kmax, int* count,
                       hipStream_t st);
 hipError_t cg_check(int64_t C, const double* rsv, const double* b2, double tol2, int* done, hipStream_t st);
+
+// Two Chebyshev iterations per launch (lmc_cheb_pair.hip):  f1 = u_{k+1} = a0 cur - t0 sigma H^T H cur + b0 rhs + s0 prv,
+// f2 (or f2_last) = u_{k+2} = a1 f1 - t1 sigma H^T H f1 + b1 rhs + s1 cur.  tg = t sigma_f c_u c_v (the launcher fills cbox and folds it in).
+// The launch returns at once when *run_count <= run_index; it writes u_{k+2} to f2_last instead of f2 when force_last or *run_count <= last_index
+// (no later pair of the solve will run).  cur, prv, rhs, f1, f2, f2_last: [C][H][W]; f1, f2, f2_last distinct from the inputs.
+struct ChebPairArgs {
+  int H, W, C;
+  float cbox;
+  const float* cur;
+  const float* prv;
+  const float* rhs;
+  float* f1;
+  float* f2;
+  float* f2_last;
+  float a0, tg0, b0, s0, a1, tg1, b1, s1;
+  const int* run_count;
+  int run_index, last_index, force_last;
+};
+bool cheb_pair_supported(int H, int W, const BlurTaps& taps);
+bool cheb_pair_pays(int64_t C, int H);
+hipError_t launch_cheb_pair(ChebPairArgs a, const BlurTaps& taps, hipStream_t st);
 }  // namespace lmc
 
 namespace lmc {

@@ -253,3 +253,39 @@ def test_l2_implicit_step_spectral_bound_holds(la, tau, scale, signed):
     res = rhs - (u + ts * O.blur_adjoint(O.blur(u, h, (2, 2)), h, (2, 2)))
     for c in range(2):
         assert np.linalg.norm(res[c]) <= 5e-6 * np.linalg.norm(rhs[c]), np.linalg.norm(res[c]) / np.linalg.norm(rhs[c])
+
+
+@pytest.mark.parametrize("shape,C,band", [((72, 128), 3, 32), ((150, 512), 2, 0), ((100, 264), 40, 40), ((37, 36), 2, 0), ((300, 256), 1, 0),
+                                          ((90, 512), 2, 32)])
+def test_ulpda_two_chebyshev_iterations_per_launch(la, shape, C, band, monkeypatch):
+    """The implicit step with two Chebyshev iterations per launch (lmc_cheb_pair.hip: wave pairs, LDS hand-off, solution delivered in the sampler's
+    second array): several bands per chain, 4 and 8 pixels per lane, partially filled last lanes, warm starts over 5 iterations -- against the
+    per-chain loops of the CPU checker with the same Philox field."""
+    monkeypatch.setenv("LMC_CHEB_PAIR", "2")         # also where the launch is too small for the pairs to pay (read per solve)
+    if band:
+        monkeypatch.setenv("LMC_PAIR_BAND", str(band))       # rows per wave pair (default: >= 128)
+    sigma, tau_reg = 0.75, 0.3
+    rng = np.random.default_rng(shape[1])
+    img = np.zeros(shape); img[shape[0] // 5:shape[0] // 2, shape[1] // 6:2 * shape[1] // 3] = 150.0
+    img += np.linspace(0, 30, shape[1])[None, :]
+    h = np.ones((5, 5)) / 25
+    y = O.blur(img, h, (2, 2)) + rng.normal(0, sigma, shape)
+    seed, nit, cho = 11, 5, 3
+    l2 = la.L2(Op=la.Convolve2D(shape, h), b=y.ravel(), sigma=1 / sigma ** 2, niter=50, warm=True)
+    smp = la.ULPDASampler(l2, la.L21(sigma=tau_reg), la.Gradient(shape), shape, n_chains=C, tau=0.95 * sigma ** 2, mu=1.0, theta=1.0,
+                          gfirst=False, seed=seed, chain_offset=cho)
+    smp.step(nit)
+    assert "pairs" in smp.kernel_name, smp.kernel_name
+    got = smp.get_state().cpu().numpy()
+    goty = smp.get_dual().cpu().numpy()
+    Gop = O.Gradient(shape)
+    for c in sorted({0, C - 1, C // 2}):
+        l2o = O.L2(Op=O.Convolve2D(shape, h), b=y.ravel(), sigma=1 / sigma ** 2, niter=50, warm=True)
+        noise = np.stack([O.philox_normals(seed, k, [cho + c], *shape)[0].ravel().astype(np.float64) for k in range(nit)])
+        xs, ys = O.ulpda(l2o, O.L21(sigma=tau_reg), Gop, np.zeros(shape[0] * shape[1]), 0.95 * sigma ** 2, 1.0, theta=1.0, niter=nit,
+                         gfirst=False, returny=True, noise=noise)
+        assert rel(got[c].ravel(), xs[-1]) < 2e-4, (c, rel(got[c].ravel(), xs[-1]))
+        assert rel(goty[c].ravel(), ys[-1]) < 2e-3
+        rowerr = np.abs(got[c] - xs[-1].reshape(shape)).max(axis=1)
+        assert rowerr.max() < 0.05, (int(rowerr.argmax()), float(rowerr.max()))       # nothing special at band seams
+    smp.close()
