@@ -1207,13 +1207,16 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
       s->ev.push_back(e);
     }
   }
-  // LMC_MOMENTS_OVERLAP=1: run the moment reductions on a side stream under the following step kernel
-  // default: on for small configurations (<= 32 Mi pixel-updates per iteration, e.g. BASELINE config 2 at 256 x 256 x 128: the 15 us
-  // reduction is 40 % of a serial iteration; measured 40.2 -> 37.1 us per iteration), off for large ones (the reduction then competes with
-  // the step kernel for HBM); LMC_MOMENTS_OVERLAP = 0 / 1 forces it
+  // LMC_MOMENTS_OVERLAP=1: the moment reductions run on a side stream under the following step kernel (0: serially on the caller's stream).
+  // Default: on for small configurations (<= 32 Mi pixel-updates per iteration; BASELINE config 2 at 256 x 256 x 128: the 15 us reduction is
+  // 40 % of a serial iteration, 40.2 -> 35.9 us per iteration with 128 background workgroups), off for large ones: at the headline size the
+  // reduction under the step kernel costs that kernel 6 % (1.76 -> 1.89 ms per launch) and saves its own 0.22 ms -- 1.976 -> 1.90-1.92 ms per
+  // iteration with 256 workgroups (16: 3.19, 64: 2.07, 128: 1.92, 256: 1.90, 512: 1.94, 1024: 1.98 ms; too few and the reduction outlasts the
+  // step kernel) -- a 3.5 % gain that is left opt-in so that the step kernel's launch time in bench.py / profiles/ is that of the kernel alone.
   const char* ov_env = getenv("LMC_MOMENTS_OVERLAP");
   const bool want_overlap = ov_env ? atoi(ov_env) != 0 : (long long)s->C * s->prob.H * s->prob.W <= (1LL << 25);
-  static const int bg_wgs = [] { const char* e = getenv("LMC_MOMENTS_BG_WGS"); return e ? atoi(e) : 128; }();   // 0: the full-speed kernel
+  static const int bg_env = [] { const char* e = getenv("LMC_MOMENTS_BG_WGS"); return e ? atoi(e) : -1; }();   // 0: the full-speed kernel
+  const int bg_wgs = bg_env >= 0 ? bg_env : ((long long)s->C * s->prob.H * s->prob.W <= (1LL << 25) ? 128 : 256);
   bool overlap = want_overlap && s->moments && n_iters > 1;
   if (overlap && !s->side) {
     int prio_least = 0, prio_greatest = 0;     // lowest priority: the step kernel's workgroups go first
