@@ -125,7 +125,7 @@ typedef struct lmc_problem {
    * != 0 carries the projected TV dual (p, q) from one MYULA iteration to the next -- tv_niter in {1, 2, 3} dual iterations per
    * MYULA iteration, momentum restarted, +16 B per pixel and iteration of HBM traffic for the dual field.  SURVEY section 8(d) "K in
    * {1,3} warm-dual reported too".  lmc_sampler_set_state resets the dual to zero.  Needs the full-width pipeline kernel
-   * (132 <= W <= 512, separable blur / pointwise / no data term), otherwise LMC_E_UNSUPPORTED. */
+   * (W > 128, W % 4 == 0 up to 256 columns and W % 8 == 0 above; separable blur / pointwise / no data term), otherwise LMC_E_UNSUPPORTED. */
   int32_t tv_warm;
 } lmc_problem;
 
@@ -162,7 +162,8 @@ int lmc_fused_eval(const lmc_problem* prob, const float* x_dev, float* out_dev, 
  * pyproximal.L2.prox / algs.py:224-256 (row a8).  LMC_DATA_BLUR: iterative, started from `out` as given if warm != 0, else from zero,
  * to the relative residual of lmc_set_cg_tolerance within at most `niter` iterations (the reference: LSQR, niter=50, warm start).
  * Build-specified solver: the Chebyshev semi-iteration on the known spectrum [1, 1 + tau*sigma_f*(sum|h|)^2] where the row-streaming
- * kernel covers the blur (separable, <= 7 centred taps, W % 4 == 0, W <= 512) and the tolerance is reachable within `niter`;
+ * kernel covers the blur (separable, <= 7 centred taps, any width) and the tolerance is reachable within `niter` (ULPDA samplers run two
+ * iterations per launch where that pays: uniform 5 x 5 box, W % 4 == 0, W <= 512, n_chains * H >= 2^17);
  * conjugate gradients otherwise (then a cap that binds returns CG's truncated iterate).
  * IDENTITY / MASK / NONE: closed form.  workspace_dev: 5*n_img*H*W floats followed (8-byte aligned) by 4*n_img+1 doubles;
  * lmc_l2_prox_workspace_bytes gives the size. */
@@ -336,8 +337,9 @@ float lmc_set_cg_tolerance(float tol);
  * 1 = LDS-tiled, 2 = (removed in ABI 2: the one-group streaming pipeline; LMC_E_INVALID), 3 = the row pipeline split over two wave groups,
  * 4 = HBM-bound tiled kernel for closed-form priors, 5 = register-block kernel (stencil-free data term, prox local to
  * 8 x 8 blocks: Haar-l1 / l2 / l1 / none; H, W multiples of 8), 6 = barrier-free row streaming (separable blur + closed-form
- * prior, W <= 512, W % 4 == 0), 7 = stage-parallel full-width TV pipeline (isotropic TV with 10, 20, ... 60 dual iterations, separable
- * blur or no data term, 132 <= W <= 512: the default of the headline configuration).  Returns the previous setting (>= 0) or a
+ * prior; any width: column strips above 512 columns, dword-aligned 16-byte accesses when W % 4 != 0), 7 = stage-parallel full-width TV pipeline
+ * (isotropic TV with 10, 20, ... 60 dual iterations, separable blur or no data term, W > 128; any width for these counts, other counts -- 2, 6, 8, 9,
+ * warm-dual 1, 2, 3 -- need W % 4 == 0 up to 256 columns and W % 8 == 0 above: the default of the headline configuration).  Returns the previous setting (>= 0) or a
  * negative lmc_status.  All variants compute the same update; the switch exists for A/B tests and profiles. */
 int lmc_set_step_variant(int32_t variant);
 

@@ -982,7 +982,7 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
     if (s->base.prior_kind != LMC_PRIOR_TV_ISO || !lmc::pipe_warm_supported(probe)) {
       lmc_sampler_destroy(s);
       return fail(LMC_E_UNSUPPORTED, "tv_warm: needs tv_niter in {1, 2, 3} (after tv_lagged_output) and the full-width pipeline kernel "
-                  "(132 <= W <= 512, W %% 4 == 0 (%% 8 above 256), separable blur <= 7 taps / pointwise / no data term)");
+                  "(W > 128, W %% 4 == 0 (%% 8 above 256), separable blur <= 7 taps / pointwise / no data term)");
     }
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
       e = hipMalloc(&s->tvwarm[i], 2 * nbytes);

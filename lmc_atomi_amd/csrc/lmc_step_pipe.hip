@@ -11,8 +11,8 @@ int centred_blur_taps(const StepArgs& a, float* uc, float* vc);   // lmc_step_ro
 static bool pipe_geometry_ok(const StepArgs& a) {
   if (a.prior_kind != LMC_PRIOR_TV_ISO || a.prox_ext) return false;
   // 8 (4) pixels per lane above (up to) 256 columns; narrower than 129 columns half the lanes idle and the split kernel wins.  Any width:
-  // rows that are not 16-byte aligned (W % 4 != 0) are read and written pixel by pixel, images wider than 512 columns run as column strips of
-  // 512 with recomputed halos (the reference's 667 x 877 image: two strips) -- without the energy by-products, whose sums would count the halos.
+  // rows that are not 16-byte aligned (W % 4 != 0) use dword-aligned 16-byte accesses and per-pixel masks, images wider than 512 columns run as column
+  // strips of 512 with recomputed halos (the reference's 667 x 877 image: two strips) -- without the energy by-products, whose sums would count the halos.
   if (a.W <= 128 || a.H < 1 || a.W > 16384) return false;
   if (a.W > 512 && (a.f_out || a.g_out)) return false;
   // widths that are not a multiple of the pixels per lane (8 above 256 columns, else 4): K = 10 (and its chains) only

@@ -163,3 +163,28 @@ def test_ulpda_implicit_step_on_wide_images(la, shape):
         xs = O.ulpda(l2o, O.L21(sigma=0.3), Gop, np.zeros(shape[0] * shape[1]), 0.95 * GAMMA, 1.0, theta=1.0, niter=nit, gfirst=False, noise=noise)
         assert rel(got[c].ravel(), xs[-1]) < 2e-4, (c, rel(got[c].ravel(), xs[-1]))
     smp.close()
+
+
+@pytest.mark.parametrize("K,warm", [(9, False), (2, False), (8, False), (1, True), (2, True), (3, True)])
+def test_other_pipeline_instantiations_across_strips(la, K, warm):
+    """Odd / short dual-iteration counts and the warm-dual prox on a 1000-column image (three strips; their halo follows K)."""
+    shape = (24, 1000)
+    img, h, off, y = synth(shape, 5)
+    rng = np.random.default_rng(K)
+    C_, nit = 2, 4
+    x0 = img[None] + rng.normal(0, 8, (C_,) + shape)
+    noise = rng.standard_normal((nit, C_) + shape)
+    pf = la.L2(Op=la.Convolve2D(shape, h, offset=off), b=y, sigma=1 / SIGMA ** 2)
+    smp = la.MYULASampler(pf, la.TV(shape, sigma=0.3, niter=K, warm=warm), shape, n_chains=C_, tau=TAU, gamma=GAMMA, noise="injected")
+    smp.set_state(x0)
+    smp.step(nit, noise=noise)
+    assert "pipe" in smp.kernel_name, smp.kernel_name
+    got = smp.get_state().cpu().numpy()
+    prior = {"kind": "tv", "sigma": 0.3, "niter": K, "t": GAMMA}
+    if warm:
+        prior["warm"] = True
+    ref = O.myula_batched(x0, y, h, off, 1 / SIGMA ** 2, TAU, GAMMA, prior, nit, lambda i: noise[i])
+    assert rel(got, ref) < 3e-5, rel(got, ref)
+    colerr = np.abs(got - ref).max(axis=(0, 1))
+    assert colerr.max() < 3e-3, (int(colerr.argmax()), float(colerr.max()))
+    smp.close()
