@@ -396,10 +396,12 @@ static hipError_t chebyshev_solve(const Problem& q, float ts, float* u, const fl
   const char* pair_env = getenv("LMC_CHEB_PAIR");
   const int pair_mode = pair_env ? atoi(pair_env) : 1;
   const bool pair_on = pair_mode == 2 || (pair_mode == 1 && lmc::cheb_pair_pays(C, q.H));
-  if (pb && result && pair_on && chunk == C && K >= 3 && delta > 1e-12 * theta && lmc::cheb_pair_supported(q.H, q.W, q.taps)) {
-    // iteration 0 (with the residual statistics of the adaptive count): u -> tmp; then pairs p = 1 .. M of iterations 2p - 1, 2p
-    const int M = K / 2;                                       // K even (adaptive) or odd: 1 + 2M >= K iterations at most
-    const int n_it = 1 + 2 * M;
+  if (pb && result && pair_on && chunk == C && K >= 4 && delta > 1e-12 * theta && lmc::cheb_pair_supported(q.H, q.W, q.taps)) {
+    // pairs p = 1 .. M of iterations 2p - 2, 2p - 1.  The first one also forms the residual statistics of iteration 0 (the adaptive count, known
+    // after it); the second always runs (the solution has to arrive in pb->out, and the first cannot know whether it is the last); pair p >= 3
+    // returns at once when count <= 2p - 2; the last pair that runs writes to pb->out.
+    const int M = (K + 1) / 2;
+    const int n_it = 2 * M;
     std::vector<double> al(n_it), be(n_it);
     {
       double rho = delta / theta;
@@ -414,37 +416,35 @@ static hipError_t chebyshev_solve(const Problem& q, float ts, float* u, const fl
     }
     double* stat = scal;
     int* count = reinterpret_cast<int*>(scal + 4 * C);
-    A.x_in = u; A.x_out = tmp;
-    A.a = (float)(1.0 - al[0]); A.t = (float)(al[0] * (double)ts / (double)q.sigma_f); A.b = (float)al[0];
-    A.noise_mode = LMC_NOISE_NONE; A.noise = zero_y; A.s = 0.f;
-    A.dot_out = adaptive ? stat : nullptr; A.dot_mode = adaptive ? 1 : 0; A.run_count = nullptr; A.run_index = 0;
-    hipError_t e = lmc::launch_step_rows(A, st);
-    if (e != hipSuccess) return e;
-    if (adaptive) {
-      const double sk = std::sqrt(lmax / lmin), c = (sk - 1.0) / (sk + 1.0);
-      e = lmc::cheb_count(C, stat, 1.0 / ((double)A.b * (double)A.b), (double)tol, 1.0 / std::log(1.0 / c), K, count, st);
-      if (e != hipSuccess) return e;
-    }
-    float* cur = tmp;
-    float* prv = u;
-    float* f1 = pb->b1;
-    float* f2 = pb->b2;
+    const float* cur = u;
+    const float* prv = u;          // iteration 0 has no u_{-1} (s0 = 0): any valid array
+    float* f1 = tmp;
+    float* f2 = pb->b1;
+    float* spare = pb->b2;
     for (int p = 1; p <= M; ++p) {
-      const int k0 = 2 * p - 1, k1 = 2 * p;
+      const int k0 = 2 * p - 2, k1 = 2 * p - 1;
       lmc::ChebPairArgs P;
       std::memset(&P, 0, sizeof P);
       P.H = q.H; P.W = q.W; P.C = (int)C;
-      P.cur = cur; P.prv = prv; P.rhs = rhs; P.f1 = f1; P.f2 = f2; P.f2_last = pb->out;
+      P.cur = cur; P.prv = prv; P.rhs = rhs; P.f1 = f1; P.f2 = f2; P.f2_last = p == 1 ? f2 : pb->out;
       P.a0 = (float)(1.0 - al[k0] + be[k0]); P.tg0 = (float)(al[k0] * (double)ts); P.b0 = (float)al[k0]; P.s0 = (float)(-be[k0]);
       P.a1 = (float)(1.0 - al[k1] + be[k1]); P.tg1 = (float)(al[k1] * (double)ts); P.b1 = (float)al[k1]; P.s1 = (float)(-be[k1]);
-      P.run_count = adaptive ? count : nullptr;
-      P.run_index = p == 1 ? -1 : k0;           // the first pair always runs (the solution has to arrive in pb->out)
-      P.last_index = k1 + 1;                    // no later pair runs when *count <= 2p + 1
+      P.run_count = adaptive && p >= 2 ? count : nullptr;
+      P.run_index = p <= 2 ? -1 : k0;           // *count <= k0: iterations k0, k0 + 1 are not needed
+      P.last_index = k1 + 1;                    // no later pair runs when *count <= 2p
       P.force_last = p == M;
-      e = lmc::launch_cheb_pair(P, q.taps, st);
+      P.dot_out = adaptive && p == 1 ? stat : nullptr;
+      hipError_t e = lmc::launch_cheb_pair(P, q.taps, st);
       if (e != hipSuccess) return e;
-      float* oc = cur; float* op = prv;
-      cur = f2; prv = f1; f1 = oc; f2 = op;
+      if (adaptive && p == 1) {
+        const double sk = std::sqrt(lmax / lmin), c = (sk - 1.0) / (sk + 1.0);
+        e = lmc::cheb_count(C, stat, 1.0 / ((double)P.b0 * (double)P.b0), (double)tol, 1.0 / std::log(1.0 / c), 2 * M, count, st);
+        if (e != hipSuccess) return e;
+      }
+      // u_{k+2} = f2 and u_{k+1} = f1 are the next pair's inputs; the arrays it read are free again (u itself from the second pair on)
+      float* free_a = p == 1 ? spare : const_cast<float*>(cur);
+      float* free_b = p == 1 ? u : const_cast<float*>(prv);
+      cur = f2; prv = f1; f1 = free_a; f2 = free_b;
     }
     *result = pb->out;
     return hipSuccess;

@@ -33,7 +33,7 @@ __device__ __forceinline__ void pair_gload(float (&dst)[PXL], const float* __res
   }
 }
 
-template <int PXL, int STAGE>
+template <int PXL, int STAGE, bool DOT>
 __device__ __forceinline__ void cheb_pair_body(const ChebPairArgs& P, const int band_rows, const int nbands, const bool last, float* __restrict__ ringU,
                                                float* __restrict__ ringE) {
   constexpr int HW = 2, LAG = 4, PF = 4, ULO = 0, UHI = 4;
@@ -78,6 +78,8 @@ __device__ __forceinline__ void cheb_pair_body(const ChebPairArgs& P, const int 
       pair_gload<PXL>(xr[p], xin + (size_t)min(max(base_first + p, 0), H - 1) * W, c0, W);
     });
   }
+
+  double dacc = 0.0, dacc2 = 0.0;       // DOT (stage 0 of a solve's first pair): sum (u_{k+1} - u_k)^2 and sum rhs^2 over the rows this pair writes
 
   // One step: stage 0 takes input row base + J, stage 1 input row base + J - 8 (both have slot J).
   auto step = [&](auto jj, const int base) __attribute__((always_inline)) {
@@ -192,6 +194,13 @@ __device__ __forceinline__ void cheb_pair_body(const ChebPairArgs& P, const int 
               const float x = xr[so][4 * g + q];
               u1[q] = fmaf(P.a0, x, fmaf(-P.tg0, Ws[4 * g + q], fmaf(P.b0, rr[q], P.s0 * pp[q])));
               ee[q] = fmaf(P.a1, u1[q], fmaf(P.b1, rr[q], P.s1 * x));
+              if constexpr (DOT) {
+                if (mine) {
+                  const double d = (double)u1[q] - (double)x;
+                  dacc = fma(d, d, dacc);
+                  dacc2 = fma((double)rr[q], (double)rr[q], dacc2);
+                }
+              }
             }
             *reinterpret_cast<float4*>(myU + so * 64 * PXL + 4 * g) = make_float4(u1[0], u1[1], u1[2], u1[3]);
             *reinterpret_cast<float4*>(myE + so * 64 * PXL + 4 * g) = make_float4(ee[0], ee[1], ee[2], ee[3]);
@@ -223,17 +232,21 @@ __device__ __forceinline__ void cheb_pair_body(const ChebPairArgs& P, const int 
     static_for<4, 8>([&](auto jj) { step(jj, base); });
     __syncthreads();
   }
+  if constexpr (DOT && stage == 0) {
+    const double t1 = wave_sum(dacc), t2 = wave_sum(dacc2);
+    if (lane == 0) { unsafeAtomicAdd(&P.dot_out[2 * chain], t1); unsafeAtomicAdd(&P.dot_out[2 * chain + 1], t2); }
+  }
 }
 
 
-template <int PXL>
+template <int PXL, bool DOT>
 __global__ __launch_bounds__(128, 2) void cheb_pair_kernel(const ChebPairArgs P, const int band_rows, const int nbands) {
   if (P.run_count && *P.run_count <= P.run_index) return;      // iterations the warm-started solve turned out not to need (uniform)
   const bool last = P.force_last || (P.run_count && *P.run_count <= P.last_index);
   __shared__ float ringU[8 * 64 * PXL], ringE[8 * 64 * PXL];
   // one instantiation per wave: each keeps its own register rings, and both pass the same sequence of barriers
-  if ((threadIdx.x >> 6) == 0) cheb_pair_body<PXL, 0>(P, band_rows, nbands, last, ringU, ringE);
-  else cheb_pair_body<PXL, 1>(P, band_rows, nbands, last, ringU, ringE);
+  if ((threadIdx.x >> 6) == 0) cheb_pair_body<PXL, 0, DOT>(P, band_rows, nbands, last, ringU, ringE);
+  else cheb_pair_body<PXL, 1, false>(P, band_rows, nbands, last, ringU, ringE);
 }
 
 // The pair kernel covers: the uniform 5-tap box (the reference's 5 x 5 blur, window [0, 4] of the centred taps), 16-byte aligned rows, one wave
@@ -273,8 +286,11 @@ hipError_t launch_cheb_pair(ChebPairArgs a, const BlurTaps& taps, hipStream_t st
   const int nbands = (a.H + band - 1) / band;
   const long long wgs = (long long)a.C * nbands;
   if (wgs > 0x7fffffffLL) return hipErrorInvalidConfiguration;
-  if (a.W <= 256) hipLaunchKernelGGL(cheb_pair_kernel<4>, dim3((unsigned)wgs), dim3(128), 0, st, a, band, nbands);
-  else hipLaunchKernelGGL(cheb_pair_kernel<8>, dim3((unsigned)wgs), dim3(128), 0, st, a, band, nbands);
+  if (a.dot_out) {     // the first pair of a solve: residual statistics of its first iteration (chebyshev_solve's adaptive count)
+    if (a.W <= 256) hipLaunchKernelGGL((cheb_pair_kernel<4, true>), dim3((unsigned)wgs), dim3(128), 0, st, a, band, nbands);
+    else hipLaunchKernelGGL((cheb_pair_kernel<8, true>), dim3((unsigned)wgs), dim3(128), 0, st, a, band, nbands);
+  } else if (a.W <= 256) hipLaunchKernelGGL((cheb_pair_kernel<4, false>), dim3((unsigned)wgs), dim3(128), 0, st, a, band, nbands);
+  else hipLaunchKernelGGL((cheb_pair_kernel<8, false>), dim3((unsigned)wgs), dim3(128), 0, st, a, band, nbands);
   return hipGetLastError();
 }
 

@@ -118,6 +118,7 @@ struct ChebPairArgs {
   float a0, tg0, b0, s0, a1, tg1, b1, s1;
   const int* run_count;
   int run_index, last_index, force_last;
+  double* dot_out;      // non-NULL: dot_out[2c] += sum (f1 - cur)^2, dot_out[2c+1] += sum rhs^2 (the statistics the adaptive iteration count is made from)
 };
 bool cheb_pair_supported(int H, int W, const BlurTaps& taps);
 bool cheb_pair_pays(int64_t C, int H);
