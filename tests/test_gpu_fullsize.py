@@ -149,3 +149,39 @@ def test_fullsize_run_to_run_determinism(la):
     # the moment images are sums of fp64 atomics (order varies): equal to rounding
     assert rel(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy()) < 1e-12
     assert torch.isfinite(outs[0][0]).all()
+
+
+def test_fullsize_ulpda_pairs_agree_with_single_launches_and_one_chain_alone(la, monkeypatch):
+    """ULPDA at 512 x 512 x 512 chains (where the two-iterations-per-launch Chebyshev solve is the default): the same trajectory as with
+    single-iteration launches (both solve the implicit step to 1e-6), and chain 300 of the batch equals that chain run alone (one band per
+    chain in the batch, four in the solo run: the result does not depend on the band layout)."""
+    import torch
+    shape = (512, 512)
+    img = scene(shape)
+    h = np.ones((5, 5)) / 25
+    rng = np.random.default_rng(2)
+    y = O.blur(img, h, (2, 2)) + rng.normal(0, 0.75, shape)
+    C, nit, seed = 512, 3, 21
+
+    def run(n_chains, offset):
+        l2 = la.L2(Op=la.Convolve2D(shape, h), b=y.ravel(), sigma=1 / 0.5625, niter=50, warm=True)
+        smp = la.ULPDASampler(l2, la.L21(sigma=0.3), la.Gradient(shape), shape, n_chains=n_chains, tau=0.95 * 0.5625, mu=1.0, theta=1.0,
+                              gfirst=False, seed=seed, chain_offset=offset)
+        smp.step(nit)
+        name = smp.kernel_name
+        x = smp.get_state()
+        out = x[[0, 300 - offset if offset == 0 else 0, -1]].cpu().numpy() if n_chains > 1 else x.cpu().numpy()
+        smp.close()
+        torch.cuda.empty_cache()
+        return out, name
+
+    pairs, name = run(C, 0)
+    assert "pairs" in name, name
+    monkeypatch.setenv("LMC_CHEB_PAIR", "0")
+    single, name0 = run(C, 0)
+    assert "pairs" not in name0
+    assert rel(pairs, single) < 2e-5, rel(pairs, single)
+    monkeypatch.setenv("LMC_CHEB_PAIR", "2")
+    solo, name1 = run(1, 300)
+    assert "pairs" in name1
+    assert rel(solo[0], pairs[1]) < 2e-5, rel(solo[0], pairs[1])
