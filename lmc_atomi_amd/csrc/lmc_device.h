@@ -135,6 +135,24 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 // Pixels c .. c+3 of a row of W >= 4 floats -> d[0..3], one 16-byte access that never leaves the row: the group that holds the row end
 // (c < W < c + 4) reads the last four floats of the row and moves them down by 4 - W % 4 (wave-uniform) places; a group past the row reads its
 // start.  Elements at columns >= W come back undefined: every caller masks per pixel.
+__device__ __forceinline__ void load4_dword_aligned_raw(float& d0, float& d1, float& d2, float& d3, const float* __restrict__ row, int c, int W) {
+  const bool part = c < W && c + 4 > W;
+  const int cc = c + 4 <= W ? c : (part ? W - 4 : 0);
+  const f4u v = *reinterpret_cast<const f4u*>(row + cc);
+  d0 = v.x; d1 = v.y; d2 = v.z; d3 = v.w;
+}
+// ... and the move into place, kept apart from the load: applied where the values are USED, so that a prefetched row stays in flight (a select
+// at load time makes the wave wait for the load at once; measured on the 667 x 877 image: pipe 3.13 -> see DESIGN 3.0p, rows 1.02 ms).
+__device__ __forceinline__ void unshift4_dword_aligned(float& d0, float& d1, float& d2, float& d3, int c, int W) {
+  const bool part = c < W && c + 4 > W;
+  const int s = 4 - (W & 3);
+  const float v1 = d1, v2 = d2, v3 = d3;
+  d0 = part ? (s == 1 ? v1 : (s == 2 ? v2 : v3)) : d0;
+  d1 = part ? (s == 1 ? v2 : v3) : v1;
+  d2 = part ? v3 : v2;
+}
+// load and move in one (the row-streaming kernel; written out rather than composed of the two above: the composition costs that register-bound
+// kernel 30 more spilled VGPRs)
 __device__ __forceinline__ void load4_dword_aligned(float& d0, float& d1, float& d2, float& d3, const float* __restrict__ row, int c, int W) {
   const bool part = c < W && c + 4 > W;
   const int cc = c + 4 <= W ? c : (part ? W - 4 : 0);
@@ -144,6 +162,11 @@ __device__ __forceinline__ void load4_dword_aligned(float& d0, float& d1, float&
   d1 = part ? (s == 1 ? v.z : v.w) : v.y;
   d2 = part ? v.w : v.z;
   d3 = v.w;
+}
+template <int PXL>
+__device__ __forceinline__ void unshift_row_dword_aligned(float (&r)[PXL], int c0, int W) {
+#pragma unroll
+  for (int g = 0; g < PXL / 4; ++g) unshift4_dword_aligned(r[4 * g], r[4 * g + 1], r[4 * g + 2], r[4 * g + 3], c0 + 4 * g, W);
 }
 // Pixels c .. c+3 -> row, those with columns in [lo, hi) only (hi <= W): one 16-byte store when the group is inside, else pixel by pixel.
 __device__ __forceinline__ void store4_dword_aligned(float* __restrict__ row, int c, int lo, int hi, float v0, float v1, float v2, float v3) {

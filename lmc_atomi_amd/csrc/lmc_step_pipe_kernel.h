@@ -203,8 +203,13 @@ __device__ __forceinline__ void gload_raw(float (&dst)[PXL], const float* __rest
     }
   } else {
 #pragma unroll
-    for (int g = 0; g < PXL / 4; ++g) load4_dword_aligned(dst[4 * g], dst[4 * g + 1], dst[4 * g + 2], dst[4 * g + 3], row, c0 + 4 * g, W);
+    for (int g = 0; g < PXL / 4; ++g) load4_dword_aligned_raw(dst[4 * g], dst[4 * g + 1], dst[4 * g + 2], dst[4 * g + 3], row, c0 + 4 * g, W);
   }
+}
+// ... whose consumer moves the group that holds the row end into place first (AL = false only; nothing to do for aligned rows)
+template <int PXL, bool AL>
+__device__ __forceinline__ void gfix_raw(float (&r)[PXL], int c0, int W) {
+  if constexpr (!AL) unshift_row_dword_aligned<PXL>(r, c0, W);
 }
 
 // Four pixels of a row to global memory: columns c .. c + 3, of which those in [lo, hi) are written (the interior of a column strip, and < W).
@@ -353,6 +358,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       }
       {   // row t arrives: publish it in the ring (zeros below the image); fetch row t + 4
         float xv[PXL];
+        gfix_raw<PXL, AL>(xpre[U], c0, W);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) xv[k] = (t < H && c0 + k < W) ? xpre[U][k] : 0.f;
         prow_store<PXL>(ring_row(t), lane, xv);
@@ -391,6 +397,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       float R[PXL];
       {
         const bool rowok = r >= 0 && r < H;
+        gfix_raw<PXL, AL>(ypre[U & 3], c0, W);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
           float acc = uv[0] * hxn[k];
@@ -443,6 +450,8 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
           float xi[PXL], gout[PXL];
           prow_load<PXL>(xi, ring_row(i), lane);
           const bool rowok = i >= 0 && i < H;
+          gfix_raw<PXL, AL>(ypre[U & 3], c0, W);
+          if (pw_mask) gfix_raw<PXL, AL>(mpre[U & 3], c0, W);
 #pragma unroll
           for (int k = 0; k < PXL; ++k) {
             float g = 0.f;
@@ -708,7 +717,10 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
                 xi[0] = v.x; xi[1] = v.y; xi[2] = v.z; xi[3] = v.w;
               } else load4_dword_aligned(xi[0], xi[1], xi[2], xi[3], nrow, c0 + 4 * g, W);
             }
-            if (A.extra) { ex[0] = exq[U][4 * g]; ex[1] = exq[U][4 * g + 1]; ex[2] = exq[U][4 * g + 2]; ex[3] = exq[U][4 * g + 3]; }
+            if (A.extra) {
+              ex[0] = exq[U][4 * g]; ex[1] = exq[U][4 * g + 1]; ex[2] = exq[U][4 * g + 2]; ex[3] = exq[U][4 * g + 3];
+              if constexpr (!AL) unshift4_dword_aligned(ex[0], ex[1], ex[2], ex[3], c0 + 4 * g, W);
+            }
             float ov[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

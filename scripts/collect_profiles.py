@@ -12,6 +12,8 @@ WORK = {   # tag -> (bench.py workload key, sampler kernel name)
     "warm1": ({"H": 512, "W": 512, "C": 1024, "prior": "tv", "data": "blur", "tv_iters": 1, "ncvx": "none", "tv_warm": True}, "myula_step_pipe_kernel(warm)"),
     "warm2": ({"H": 512, "W": 512, "C": 1024, "prior": "tv", "data": "blur", "tv_iters": 2, "ncvx": "none", "tv_warm": True}, "myula_step_pipe_kernel(warm)"),
     "warm3": ({"H": 512, "W": 512, "C": 1024, "prior": "tv", "data": "blur", "tv_iters": 3, "ncvx": "none", "tv_warm": True}, "myula_step_pipe_kernel(warm)"),
+    "wide877tv": ({"H": 667, "W": 877, "C": 512, "prior": "tv", "data": "blur", "tv_iters": 10, "ncvx": "none"}, "myula_step_pipe_kernel"),
+    "wide877l2": ({"H": 667, "W": 877, "C": 512, "prior": "l2", "data": "blur", "tv_iters": 10, "ncvx": "none"}, "myula_step_rows_kernel"),
 }
 entries = []
 for d in sorted(os.listdir(os.path.join(ROOT, "gpurun_out"))):

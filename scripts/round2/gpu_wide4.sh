@@ -1,0 +1,10 @@
+#!/bin/bash
+o=gpurun_out/r02wide; mkdir -p $o
+run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-hbm-probe --no-cpu-baseline --steps 30 --warmup 5 --repeats 1 "$@" > $o/$tag.json 2> $o/$tag.err || exit 1; python - $o/$tag.json $tag <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1])); r = d["roofline"]
+print(sys.argv[2], "ms/step %.3f" % d["ms_per_step"], "launch_ms", r.get("launch_ms"), r.get("kernel"), "frac %.3f" % (r.get("frac") or 0))
+PY
+}
+run a_l2_877 --size 667 --width 877 --chains 512 --prior l2
+run a_l2_301 --size 512 --width 301 --chains 1024 --prior l2
