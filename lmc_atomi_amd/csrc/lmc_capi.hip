@@ -396,7 +396,8 @@ static hipError_t chebyshev_solve(const Problem& q, float ts, float* u, const fl
   const char* pair_env = getenv("LMC_CHEB_PAIR");
   const int pair_mode = pair_env ? atoi(pair_env) : 1;
   const bool pair_on = pair_mode == 2 || (pair_mode == 1 && lmc::cheb_pair_pays(C, q.H));
-  if (pb && result && pair_on && chunk == C && K >= 4 && delta > 1e-12 * theta && lmc::cheb_pair_supported(q.H, q.W, q.taps)) {
+  if (pb && result && pair_on && chunk == C && K >= 4 && 2 * ((K + 1) / 2) <= niter_cap && delta > 1e-12 * theta &&
+      lmc::cheb_pair_supported(q.H, q.W, q.taps)) {      // (pairs never run more iterations than the caller's cap)
     // pairs p = 1 .. M of iterations 2p - 2, 2p - 1.  The first one also forms the residual statistics of iteration 0 (the adaptive count, known
     // after it); the second always runs (the solution has to arrive in pb->out, and the first cannot know whether it is the last); pair p >= 3
     // returns at once when count <= 2p - 2; the last pair that runs writes to pb->out.
