@@ -204,11 +204,15 @@ int load_problem(const lmc_problem* p, Problem& q) {
   }
   if (p->prior_kind != LMC_PRIOR_NONE && !(p->prior_sigma >= 0.f)) return fail(LMC_E_INVALID, "prior_sigma must be >= 0");
   if (p->ncvx_kind != LMC_NCVX_NONE) {
-    if (p->ncvx_kind != LMC_NCVX_MC_TV && p->ncvx_kind != LMC_NCVX_ME_TV) return fail(LMC_E_INVALID, "unknown ncvx_kind %d", p->ncvx_kind);
+    if (p->ncvx_kind != LMC_NCVX_MC_TV && p->ncvx_kind != LMC_NCVX_ME_TV && p->ncvx_kind != LMC_NCVX_MC_TV_ANISO)
+      return fail(LMC_E_INVALID, "unknown ncvx_kind %d", p->ncvx_kind);
     if (!(p->ncvx_gamma > 0.f)) return fail(LMC_E_INVALID, "ncvx_gamma must be > 0");
     if (p->ncvx_kind == LMC_NCVX_ME_TV && (p->ncvx_niter < 1 || p->ncvx_niter > lmc::kMaxTvIters))
       return fail(LMC_E_INVALID, "ncvx_niter %d outside 1..%d", p->ncvx_niter, lmc::kMaxTvIters);
     q.ncvx_kind = p->ncvx_kind; q.ncvx_lambda = p->ncvx_lambda; q.ncvx_gamma = p->ncvx_gamma;
+    // anisotropic MC-TV: inside the library the same kind with a NEGATIVE gamma -- mc_tv_grad (lmc_device.h) and the energy kernels take
+    // the sign as "component-wise weights 1 / max(|d|, gamma)" instead of the pixel norm; every MC-TV code path serves both
+    if (p->ncvx_kind == LMC_NCVX_MC_TV_ANISO) { q.ncvx_kind = LMC_NCVX_MC_TV; q.ncvx_gamma = -p->ncvx_gamma; }
     q.ncvx_niter = p->ncvx_niter - ((p->ncvx_kind == LMC_NCVX_ME_TV && p->tv_lagged_output) ? 1 : 0);
   }
   if (p->step_variant < 0 || p->step_variant > 7 || p->step_variant == 2)

@@ -83,19 +83,37 @@ __device__ __forceinline__ int xcd_logical_block(int b, int nblk) {
 // ---- MC-TV term of algs.L2_ncvx_tv.grad (algs.py:273-277): A^T( A x / max(|A x|, gamma) ) at pixel (i,j) ----------
 // x_rc: x at row offset r (m = -1, 0 = same, p = +1) and column offset c.  has_*: the neighbour exists inside the image.
 // |A x| = 0 is mapped to 1e-9 by the reference before min(1/gamma, 1/|A x|): identical to 1/max(|A x|, gamma).
+// gamma < 0 (wave-uniform): the ANISOTROPIC branches (algs.py:218-219, 278-279) with |gamma|: A^T( (v - soft(v, gamma)) / gamma ) = A^T of
+// v_i / max(|v_i|, gamma) component by component -- the weight of a difference depends on that difference alone.
 __device__ __forceinline__ float mc_tv_grad(float xm0, float xmp, float x0m, float x00, float x0p, float xpm, float xp0,
                                             bool has_up, bool has_down, bool has_left, bool has_right, float gamma) {
+  const bool an = gamma < 0.f;
+  const float g = fabsf(gamma);
   // weights and differences at (i,j), (i-1,j), (i,j-1)
   const float dx00 = has_down ? xp0 - x00 : 0.f, dy00 = has_right ? x0p - x00 : 0.f;
-  const float w00 = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(fmaf(dx00, dx00, dy00 * dy00)), gamma));
   const float dxm0 = has_up ? x00 - xm0 : 0.f;                       // (i-1,j) always has a row below it
   const float dym0 = (has_up && has_right) ? xmp - xm0 : 0.f;
-  const float wm0 = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(fmaf(dxm0, dxm0, dym0 * dym0)), gamma));
   const float dy0m = has_left ? x00 - x0m : 0.f;                     // (i,j-1) always has a column to its right
   const float dx0m = (has_left && has_down) ? xpm - x0m : 0.f;
-  const float w0m = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(fmaf(dx0m, dx0m, dy0m * dy0m)), gamma));
+  if (an) {
+    const float wx00 = __builtin_amdgcn_rcpf(fmaxf(fabsf(dx00), g)), wy00 = __builtin_amdgcn_rcpf(fmaxf(fabsf(dy00), g));
+    const float wxm0 = __builtin_amdgcn_rcpf(fmaxf(fabsf(dxm0), g)), wy0m = __builtin_amdgcn_rcpf(fmaxf(fabsf(dy0m), g));
+    return -((wx00 * dx00 - wxm0 * dxm0) + (wy00 * dy00 - wy0m * dy0m));
+  }
+  const float w00 = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(fmaf(dx00, dx00, dy00 * dy00)), g));
+  const float wm0 = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(fmaf(dxm0, dxm0, dym0 * dym0)), g));
+  const float w0m = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(fmaf(dx0m, dx0m, dy0m * dy0m)), g));
   // A^T v = -div v
   return -((w00 * dx00 - wm0 * dxm0) + (w00 * dy00 - w0m * dy0m));
+}
+
+// Moreau envelope of |.| (Huber) at the gradient (dx, dy) of a pixel: of the pixel norm (gamma > 0, algs.py:173-190) or of each component
+// (gamma < 0: the anisotropic branch, |gamma|)
+__device__ __forceinline__ double mc_tv_envelope(float dx, float dy, float gamma) {
+  const double g = fabsf(gamma);
+  auto hub = [&](double e) { return e <= g ? 0.5 * e * e / g : e - 0.5 * g; };
+  if (gamma < 0.f) return hub(fabsf(dx)) + hub(fabsf(dy));
+  return hub(sqrtf(fmaf(dx, dx, dy * dy)));
 }
 
 // ---- shared by the streaming step kernels ---------------------------------------------------------

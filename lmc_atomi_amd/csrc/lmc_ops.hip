@@ -353,9 +353,7 @@ __global__ __launch_bounds__(256) void energy_kernel(const float* __restrict__ x
     if (E.ncvx_kind == LMC_NCVX_MC_TV) {   // Moreau envelope of |.| at |grad x|: Huber, subtracted with weight lambda
       const float dx = (r + 1 < H) ? xi[p + W] - v : 0.f;
       const float dy = (c + 1 < W) ? xi[p + 1] - v : 0.f;
-      const float e = sqrtf(fmaf(dx, dx, dy * dy));
-      const double hub = e <= E.ncvx_gamma ? 0.5 * (double)e * e / E.ncvx_gamma : (double)e - 0.5 * E.ncvx_gamma;
-      na += hub;
+      na += mc_tv_envelope(dx, dy, E.ncvx_gamma);
     }
     if (E.prior_kind == LMC_PRIOR_TV_ISO) {
       const float dx = (r + 1 < H) ? xi[p + W] - v : 0.f;
@@ -431,8 +429,7 @@ __global__ __launch_bounds__(256) void energy_sep_kernel(const float* __restrict
       const float dx = (gr + 1 < H) ? xs[(HL + lr + 1) * PW + HL + tx] - v : 0.f;
       const float dy = (gc + 1 < W) ? xs[(HL + lr) * PW + HL + tx + 1] - v : 0.f;
       if (E.ncvx_kind == LMC_NCVX_MC_TV) {
-        const float e = sqrtf(fmaf(dx, dx, dy * dy));
-        na += e <= E.ncvx_gamma ? 0.5 * (double)e * e / E.ncvx_gamma : (double)e - 0.5 * E.ncvx_gamma;
+        na += mc_tv_envelope(dx, dy, E.ncvx_gamma);
       }
       if (E.prior_kind == LMC_PRIOR_TV_ISO) ga += (double)sqrtf(fmaf(dx, dx, dy * dy));
       else if (E.prior_kind == LMC_PRIOR_TV_ANISO) ga += (double)fabsf(dx) + (double)fabsf(dy);

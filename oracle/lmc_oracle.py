@@ -587,9 +587,10 @@ class L2NcvxTV(_Prox):
     """Restatement of the in-repo class ``L2_ncvx_tv`` (``algs.py:22-291``):
     ``f(x) = sigma/2||Op x - b||^2 - lamda * env_gamma(g)(Op2 x)``.
 
-    Only the branches exercised by ``prox_lmc_deconv.py:106-113`` are restated:
-    MC-TV isotropic (``Op2 = Gradient``, ``isotropic=True``; value ``algs.py:173-190``,
-    grad ``:273-277``) and ME-TV (``Op2 = None``; grad ``:282``), with ``q = None``.
+    Restated: the branches exercised by ``prox_lmc_deconv.py:106-113`` -- MC-TV isotropic (``Op2 = Gradient``,
+    ``isotropic=True``; value ``algs.py:173-190``, grad ``:273-277``) and ME-TV (``Op2 = None``; grad ``:282``) -- and the
+    anisotropic MC-TV branches (``isotropic=False``: value without the pixel-norm reduction, prox ``:218-219``, grad
+    ``:278-279``), with ``q = None``.  (Anisotropic ME-TV is a 1-D TV over the flattened image, ``:170``: not restated.)
     """
 
     def __init__(self, dims, Op=None, Op2=None, b=None, sigma=1.0, lamda=1.0, gamma=0.5,
@@ -622,6 +623,8 @@ class L2NcvxTV(_Prox):
     def grad_moreau(self, x):                            # algs.py:271-282
         if self.Op2 is not None:
             Op2x = self.Op2.matvec(x)
+            if not self.isotropic:                       # algs.py:278-279 (and the prox pre-step :218-219): component-wise
+                return self.Op2.rmatvec(Op2x - self.g_gamma.prox(Op2x, self.gamma)) / self.gamma
             e = np.linalg.norm(Op2x.reshape(self.ndim, len(Op2x) // self.ndim), axis=0)
             e = np.where(e != 0, e, 1e-9)
             return self.Op2.rmatvec(np.minimum(1 / self.gamma, np.tile(1 / e, 2)) * Op2x)

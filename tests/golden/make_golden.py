@@ -316,6 +316,44 @@ np.savez_compressed(sys.argv[2], x=x, **res)
 '''
 
 
+def gen_algs_aniso(out):
+    """Third golden set: the ANISOTROPIC MC-TV branches of the reference's ``L2_ncvx_tv`` (``isotropic=False`` with ``Op2 = Gradient``:
+    value algs.py:173-190 without the pixel-norm reduction, prox pre-step :218-219, grad :278-279) -- the reference's own class code, with
+    the oracle's L1 standing in for ``pyproximal.L1`` (a soft threshold).  Value, gradient, prox (incl. the warm-started second call) and
+    short MYULA / ULPDA trajectories driven by the class."""
+    A = load_ref("algs")
+    d = {}
+    sigma, tau_reg = 0.75, 0.3
+    L = 1.0 / sigma ** 2
+    gamma_myula = 1.0 / L
+    tau_myula = 0.2 * gamma_myula
+    tau0, mu0 = 0.95 / L, 1.0
+    for tag, ny, nx, k, seed, gam in [("a", 16, 16, 5, 0, 15.0), ("b", 20, 24, 6, 1, 4.0)]:
+        img, h, Hop, y = deconv_problem(ny, nx, k, sigma, seed)
+        d[f"{tag}_img"], d[f"{tag}_h"], d[f"{tag}_y"] = img, h, y
+        d[f"{tag}_meta"] = np.array([ny, nx, k, seed, gam])
+        Gop = O.Gradient((ny, nx))
+        x0 = np.zeros(ny * nx)
+        mk = lambda: A.L2_ncvx_tv(dims=(ny, nx), Op=Hop, Op2=Gop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=gam,
+                                  isotropic=False, niter=50, warm=True)
+        rng = np.random.default_rng(300 + seed)
+        xt = (img + rng.normal(0, 5.0, img.shape)).ravel()
+        mc = mk()
+        d[f"{tag}_x"] = xt
+        d[f"{tag}_grad"], d[f"{tag}_val"] = mc.grad(xt.copy()), np.array(mc(xt.copy()))
+        vp = (img + np.random.default_rng(400 + seed).normal(0, 5.0, img.shape)).ravel()
+        mcp = mk()
+        d[f"{tag}_prox_in"] = vp
+        d[f"{tag}_prox_out1"] = mcp.prox(vp.copy(), tau0)
+        d[f"{tag}_prox_out2"] = mcp.prox((vp + 1.0).copy(), tau0)
+        d[f"{tag}_myula"] = A.MoreauYosidaUnadjustedLangevin(mk(), O.TV((ny, nx), sigma=tau_reg, niter=10), tau=tau_myula, gamma=gamma_myula,
+                                                             x0=x0, niter=6, seed=seed)
+        d[f"{tag}_ulpda"] = A.UnadjustedLangevinPrimalDual(mk(), O.L21(ndim=2, sigma=tau_reg), Gop, tau=tau0, mu=mu0, theta=1.0, x0=x0,
+                                                           gfirst=False, niter=6, seed=seed)
+    d["params"] = np.array([sigma, tau_reg, tau_myula, gamma_myula, tau0, mu0])
+    np.savez_compressed(out, **d)
+
+
 def gen_pywt(out):
     """Independent check of the Haar-l1 prox (BASELINE config 5's prior) with PyWavelets from the conda interpreter."""
     py39 = "/opt/conda/bin/python3.9"
@@ -347,6 +385,7 @@ if __name__ == "__main__":
     gen_prox(os.path.join(HERE, "prox.npz"))
     gen_algs(os.path.join(HERE, "algs.npz"))
     gen_algs_rtol(os.path.join(HERE, "algs_rtol.npz"))
+    gen_algs_aniso(os.path.join(HERE, "algs_aniso.npz"))
     gen_chambolle(os.path.join(HERE, "tv_chambolle.npz"))
     gen_pywt(os.path.join(HERE, "haar_pywt.npz"))
     for f in sorted(os.listdir(HERE)):

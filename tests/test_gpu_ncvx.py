@@ -100,8 +100,100 @@ def test_mc_tv_large_image_all_kernels_agree(la):
 def test_unbuilt_branches_raise(la):
     shape = (8, 8)
     H = la.Convolve2D(shape, np.ones((5, 5)) / 25)
-    with pytest.raises(NotImplementedError):
-        la.L2_ncvx_tv(dims=shape, Op=H, Op2=la.Gradient(shape), b=np.zeros(64), isotropic=False)
+    with pytest.raises(NotImplementedError):      # anisotropic ME-TV: a 1-D TV over the flattened image (algs.py:170)
+        la.L2_ncvx_tv(dims=shape, Op=H, b=np.zeros(64), isotropic=False)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_anisotropic_mc_tv_matches_reference_class(la, golden, tag):
+    """The anisotropic MC-TV branches (isotropic=False, Op2 = Gradient; algs.py:173-190, 218-219, 278-279) against outputs of the reference's
+    own class (tests/golden/algs_aniso.npz): value, gradient, prox (cold and warm-started), and the MYULA / ULPDA trajectories it drives --
+    through every kernel that evaluates the term (tiled, split / pipe by auto)."""
+    g = golden("algs_aniso.npz")
+    sigma, tau_reg, tau_myula, gamma_myula, tau0, mu0 = [float(v) for v in g["params"]]
+    ny, nx, k, seed, gam = [float(v) for v in g[f"{tag}_meta"]]
+    ny, nx, k, seed = int(ny), int(nx), int(k), int(seed)
+    h, y = g[f"{tag}_h"], g[f"{tag}_y"]
+    H = la.Convolve2D((ny, nx), h, offset=(k // 2, k // 2))
+    G = la.Gradient((ny, nx))
+    mk = lambda: la.L2_ncvx_tv(dims=(ny, nx), Op=H, Op2=G, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=gam, isotropic=False,
+                               niter=50, warm=True)
+    xt = g[f"{tag}_x"]
+    l2o = O.L2(Op=O.Convolve2D((ny, nx), h, offset=(k // 2, k // 2)), b=y.ravel(), sigma=1 / sigma ** 2)
+    scale = (1 / sigma ** 2) * (np.linalg.norm(l2o.Op.rmatvec(l2o.Op.matvec(xt))) + np.linalg.norm(l2o.Op.rmatvec(y.ravel())))
+    for variant in ("tile", "auto"):
+        la.set_step_variant(variant)
+        mc = mk()
+        got, ref = mc.grad(xt.copy()), g[f"{tag}_grad"]
+        assert np.linalg.norm(got - ref) < 2e-7 * scale and rel(got, ref) < 1e-4, (variant, rel(got, ref))
+        val = float(g[f"{tag}_val"])
+        assert abs(mc(xt.copy()) - val) < 1e-5 * abs(val)
+        gx = g[f"{tag}_myula"]
+        out = la.MoreauYosidaUnadjustedLangevin(mc, la.TV((ny, nx), sigma=tau_reg, niter=10), np.zeros(ny * nx), tau=tau_myula, gamma=gamma_myula,
+                                                niter=gx.shape[0], seed=seed, rng="pcg64")
+        assert rel(out, gx) < 5e-5, (variant, rel(out, gx))
+    la.set_step_variant("auto")
+    m = mk()
+    vp = g[f"{tag}_prox_in"]
+    assert rel(m.prox(vp.copy(), tau0), g[f"{tag}_prox_out1"]) < 1e-4
+    assert rel(m.prox(vp + 1.0, tau0), g[f"{tag}_prox_out2"]) < 1e-4
+    gx = g[f"{tag}_ulpda"]
+    xs = la.UnadjustedLangevinPrimalDual(mk(), la.L21(ndim=2, sigma=tau_reg), G, tau=tau0, mu=mu0, theta=1.0, x0=np.zeros(ny * nx), gfirst=False,
+                                         niter=gx.shape[0], seed=seed, rng="pcg64")
+    assert rel(xs, gx) < 1e-4, rel(xs, gx)
+
+
+def test_anisotropic_mc_tv_on_the_pipe_and_block_kernels(la):
+    """... and where the term is evaluated inside the full-width pipeline (combine wave) and added after the block kernel (mask + Haar):
+    against the CPU checker's class gradient with injected noise."""
+    rng = np.random.default_rng(8)
+    shape = (40, 264)
+    img = np.zeros(shape); img[8:30, 40:200] = 180.0
+    img += np.linspace(0, 30, shape[1])[None, :]
+    h = np.ones((5, 5)) / 25
+    y = O.blur(img, h, (2, 2)) + rng.normal(0, 0.75, shape)
+    C_, nit = 2, 3
+    x0 = img[None] + rng.normal(0, 8, (C_,) + shape)
+    noise = rng.standard_normal((nit, C_) + shape)
+    sig, gam_m, tau = 0.75, 0.5625, 0.1125
+    for gam in (15.0, 3.0):
+        pf = la.L2_ncvx_tv(dims=shape, Op=la.Convolve2D(shape, h, offset=(2, 2)), Op2=la.Gradient(shape), b=y.ravel(), sigma=1 / sig ** 2, lamda=0.3,
+                           gamma=gam, isotropic=False)
+        of = O.L2NcvxTV(shape, Op=O.Convolve2D(shape, h, (2, 2)), Op2=O.Gradient(shape), b=y.ravel(), sigma=1 / sig ** 2, lamda=0.3, gamma=gam,
+                        isotropic=False)
+        otv = O.TV(shape, sigma=0.3, niter=10)
+        smp = la.MYULASampler(pf, la.TV(shape, sigma=0.3, niter=10), shape, n_chains=C_, tau=tau, gamma=gam_m, noise="injected")
+        smp.set_state(x0)
+        smp.step(nit, noise=noise)
+        assert "pipe" in smp.kernel_name, smp.kernel_name
+        got = smp.get_state().cpu().numpy()
+        ref = np.stack([O.myula(of, otv, x0[c].ravel(), tau, gam_m, niter=nit, noise=[noise[i, c].ravel() for i in range(nit)])[-1].reshape(shape)
+                        for c in range(C_)])
+        assert rel(got, ref) < 2e-5, (gam, rel(got, ref))
+        f, _ = smp.energies()
+        fref = np.array([of(got[c].ravel().astype(np.float64)) for c in range(C_)])
+        assert np.allclose(f.cpu().numpy(), fref, rtol=5e-5)
+        smp.close()
+    # mask + Haar-l1 + anisotropic MC-TV (the block kernel, then the stencil pass that adds the term)
+    shape = (64, 128)
+    mask = (np.random.default_rng(7).uniform(size=shape) < 0.5).astype(np.float64)
+    img = np.zeros(shape); img[10:40, 30:90] = 200.0
+    yb = mask * (img + rng.normal(0, sig, shape))
+    pf = la.L2_ncvx_tv(dims=shape, Op=la.Diagonal(mask, dims=shape), Op2=la.Gradient(shape), b=yb.ravel(), sigma=1 / sig ** 2, lamda=0.3, gamma=15.0,
+                       isotropic=False)
+    of = O.L2NcvxTV(shape, Op=O.Diagonal(mask), Op2=O.Gradient(shape), b=yb.ravel(), sigma=1 / sig ** 2, lamda=0.3, gamma=15.0, isotropic=False)
+    x0 = img[None] + rng.normal(0, 12, (2,) + shape)
+    noise = rng.standard_normal((2, 2) + shape)
+    smp = la.MYULASampler(pf, la.WaveletL1(shape, sigma=0.3), shape, n_chains=2, tau=tau, gamma=gam_m, noise="injected")
+    smp.set_state(x0)
+    x = x0.copy()
+    for it in range(2):
+        smp.step(1, noise=noise[it:it + 1])
+        gr = np.stack([of.grad(x[c].ravel().copy()).reshape(shape) for c in range(2)])
+        x = (1 - tau / gam_m) * x - tau * gr + (tau / gam_m) * O.haar_l1_prox(x, gam_m * 0.3) + np.sqrt(2 * tau) * noise[it]
+        assert rel(smp.get_state().cpu().numpy(), x) < 5e-6 * (it + 1)
+    assert "block" in smp.kernel_name
+    smp.close()
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])

@@ -275,3 +275,35 @@ def test_tv_rtol_exit_statistics():
         g = (1 / sigma ** 2) * O.blur_adjoint(O.blur(x, h, (2, 2)) - y, h, (2, 2))
         x = (1 - tau / gamma) * x - tau * g + tau / gamma * px + np.sqrt(2 * tau) * rng.standard_normal((ny, nx))
     assert 2 <= min(exits) and max(exits) <= 6, exits
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_l2_ncvx_tv_anisotropic_mc_tv_matches_reference_class(golden, tag):
+    """The anisotropic MC-TV branches of the reference's ``L2_ncvx_tv`` (``isotropic=False``, ``Op2 = Gradient``: algs.py:173-190 without
+    the pixel-norm reduction, :218-219, :278-279) against outputs of the reference class itself (tests/golden/algs_aniso.npz): value and
+    gradient to round-off, the MYULA trajectory driven by the class bit for bit, prox / ULPDA at the accuracy of the reference's LSQR."""
+    g = golden("algs_aniso.npz")
+    sigma, tau_reg, tau_myula, gamma_myula, tau0, mu0 = g["params"]
+    ny, nx, k, seed, gam = g[f"{tag}_meta"]
+    ny, nx, k, seed = int(ny), int(nx), int(k), int(seed)
+    Hop = O.Convolve2D((ny, nx), g[f"{tag}_h"], (k // 2, k // 2))
+    Gop = O.Gradient((ny, nx))
+    y = g[f"{tag}_y"]
+    mk = lambda: O.L2NcvxTV((ny, nx), Op=Hop, Op2=Gop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=float(gam), isotropic=False, niter=50)
+    xt = g[f"{tag}_x"]
+    mc = mk()
+    np.testing.assert_allclose(mc.grad(xt.copy()), g[f"{tag}_grad"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(mc(xt.copy()), g[f"{tag}_val"], rtol=1e-12)
+    gx = g[f"{tag}_myula"]
+    out = O.myula(mk(), O.TV((ny, nx), sigma=tau_reg, niter=10), np.zeros(ny * nx), tau_myula, gamma_myula, niter=gx.shape[0], seed=seed)
+    np.testing.assert_allclose(out, gx, rtol=1e-12, atol=1e-11)
+
+    def rel(a, b):
+        return np.linalg.norm(a - b) / np.linalg.norm(b)
+    m = mk()
+    vp = g[f"{tag}_prox_in"]
+    assert rel(m.prox(vp.copy(), tau0), g[f"{tag}_prox_out1"]) < 5e-5
+    assert rel(m.prox((vp + 1.0).copy(), tau0), g[f"{tag}_prox_out2"]) < 5e-5
+    gx = g[f"{tag}_ulpda"]
+    xs = O.ulpda(mk(), O.L21(ndim=2, sigma=tau_reg), Gop, np.zeros(ny * nx), tau0, mu0, theta=1.0, niter=gx.shape[0], seed=seed, gfirst=False)
+    assert rel(xs, gx) < 5e-5, rel(xs, gx)
