@@ -63,7 +63,8 @@ __device__ __forceinline__ void cheb_pair_body(const ChebPairArgs& P, const int 
   // between request and use
   float rq[stage == 0 ? 2 : 1][PXL], pq[stage == 0 ? 2 : 1][PXL];
 #pragma unroll
-  for (int k = 0; k < PXL; ++k) { rq[0][k] = 0.f; pq[0][k] = 0.f; }
+  for (int k = 0; k < PXL; ++k) { rq[0][k] = 0.f; pq[0][k] = 0.f; if constexpr (stage == 0) { rq[1][k] = 0.f; pq[1][k] = 0.f; } }
+  const bool has_prv = P.s0 != 0.f;
 #pragma unroll
   for (int k = 0; k < PXL; ++k) Vs[k] = Ws[k] = 0.f;
 #pragma unroll
@@ -88,7 +89,7 @@ __device__ __forceinline__ void cheb_pair_body(const ChebPairArgs& P, const int 
     if constexpr (stage == 0) {
       const size_t gn = (size_t)min(max(i + 1 - LAG, 0), H - 1) * W;
       pair_gload<PXL>(rq[(J + 1) & 1], rhs + gn, c0, W);
-      pair_gload<PXL>(pq[(J + 1) & 1], prv + gn, c0, W);
+      if (has_prv) pair_gload<PXL>(pq[(J + 1) & 1], prv + gn, c0, W);       // iteration 0 has no u_{-1} (s0 = 0): pq stays zero
     }
     // (1) input row: zero outside the image (and, stage 1, outside what stage 0 published)
     float xm[PXL];
