@@ -341,8 +341,8 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       for (int u = 0; u < 2; ++u) {
         const int rs = u - E - 1;
 #pragma unroll
-        for (int f = 0; f < nsf; ++f)
-          gload_row<PXL>(spre[u][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H, al);
+        for (int f = 0; f < nsf; ++f)      // raw: masked where the row is handed over (a select here would wait for the load at once)
+          gload_raw<PXL>(spre[u][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, al);
       }
     }
     double facc = 0.0;        // sum of squared residuals (A.f_out)
@@ -366,12 +366,20 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       }
       if constexpr (CHAIN) {   // dual state row t - E - 1 of the previous link -> stage 1's hand-off slot P (read next tick)
         float* hb = lds + L::o_hand0 + P * 4 * BW;
+        const int rh = t - E - 1;                                  // the row fetched two ticks ago
+        const bool rowok_h = sin && rh >= 0 && rh < H;
 #pragma unroll
-        for (int f = 0; f < nsf; ++f) prow_store<PXL>(hb + f * BW, lane, spre[P][f]);
+        for (int f = 0; f < nsf; ++f) {
+          gfix_raw<PXL, AL>(spre[P][f], c0, W);
+          float sv[PXL];
+#pragma unroll
+          for (int k = 0; k < PXL; ++k) sv[k] = (rowok_h && c0 + (AL ? (k & ~3) : k) < W) ? spre[P][f][k] : 0.f;
+          prow_store<PXL>(hb + f * BW, lane, sv);
+        }
         const int rs = t + 2 - E - 1;
 #pragma unroll
         for (int f = 0; f < nsf; ++f)
-          gload_row<PXL>(spre[P][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, sin && rs >= 0 && rs < H, al);
+          gload_raw<PXL>(spre[P][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, al);
       }
       if constexpr (KT > 0) {
       const int i = t + 1 - D + (KT - 1);       // blur input row (<= t-1: published in an earlier tick)
