@@ -334,11 +334,14 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     // (warm dual, A.tv_warm: the state is the projected dual (p, q) of the previous MYULA iteration, two fields; it enters stage 1 as
     // both the extrapolated and the projected iterate -- the momentum restarts, beta_1 = 0)
     constexpr int nsf = CHAIN ? (WARM ? 2 : 4) : 0;           // fields per pixel of the incoming state
-    float spre[CHAIN ? 2 : 1][CHAIN ? nsf : 1][CHAIN ? PXL : 1];
+    // state rows are fetched kSPF = 2 ticks ahead (4 for the two-field warm dual was measured: K = 1 / 2 / 3: 1.43 / 1.55 / 2.18 ms against
+    // 1.44 / 1.41 / 2.13 -- the 32 extra VGPRs cost more than the deeper prefetch gains)
+    constexpr int kSPF = 2;
+    float spre[CHAIN ? kSPF : 1][CHAIN ? nsf : 1][CHAIN ? PXL : 1];
     const float* const sin = CHAIN && A.tv_in ? A.tv_in + (size_t)chain * nsf * img : nullptr;
     if constexpr (CHAIN) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < kSPF; ++u) {
         const int rs = u - E - 1;
 #pragma unroll
         for (int f = 0; f < nsf; ++f)      // raw: masked where the row is handed over (a select here would wait for the load at once)
@@ -366,20 +369,21 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       }
       if constexpr (CHAIN) {   // dual state row t - E - 1 of the previous link -> stage 1's hand-off slot P (read next tick)
         float* hb = lds + L::o_hand0 + P * 4 * BW;
-        const int rh = t - E - 1;                                  // the row fetched two ticks ago
+        constexpr int SP = U & (kSPF - 1);
+        const int rh = t - E - 1;                                  // the row fetched kSPF ticks ago
         const bool rowok_h = sin && rh >= 0 && rh < H;
 #pragma unroll
         for (int f = 0; f < nsf; ++f) {
-          gfix_raw<PXL, AL>(spre[P][f], c0, W);
+          gfix_raw<PXL, AL>(spre[SP][f], c0, W);
           float sv[PXL];
 #pragma unroll
-          for (int k = 0; k < PXL; ++k) sv[k] = (rowok_h && c0 + (AL ? (k & ~3) : k) < W) ? spre[P][f][k] : 0.f;
+          for (int k = 0; k < PXL; ++k) sv[k] = (rowok_h && c0 + (AL ? (k & ~3) : k) < W) ? spre[SP][f][k] : 0.f;
           prow_store<PXL>(hb + f * BW, lane, sv);
         }
-        const int rs = t + 2 - E - 1;
+        const int rs = t + kSPF - E - 1;
 #pragma unroll
         for (int f = 0; f < nsf; ++f)
-          gload_raw<PXL>(spre[P][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, al);
+          gload_raw<PXL>(spre[SP][f], sin ? sin + (size_t)f * img + (size_t)min(max(rs, 0), H - 1) * W : xin, c0, W, al);
       }
       if constexpr (KT > 0) {
       const int i = t + 1 - D + (KT - 1);       // blur input row (<= t-1: published in an earlier tick)
