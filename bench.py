@@ -278,7 +278,8 @@ def main():
             peak_measured = float(g.value)
         value = C * world * args.steps / elapsed
         per_launch_ms = kern_ms / launches
-        achieved = BYTES_PER_PIXEL_STEP * H * W * C / (per_launch_ms * 1e-3) / 1e9
+        its_per_launch = args.steps / launches if timed_launches else 1.0      # 2 where a launch advances every chain by two iterations
+        achieved = BYTES_PER_PIXEL_STEP * H * W * C * its_per_launch / (per_launch_ms * 1e-3) / 1e9
         prior_desc = (f"isotropic TV prox K={args.tv_iters}{' warm-dual' if args.tv_warm else ''}{' lagged output' if args.tv_lagged else ''} (tau_reg={tau_reg})" if args.prior == "tv"
                       else f"{args.prior} prior")
         out = {
@@ -319,7 +320,8 @@ def main():
                 "traffic": traffic,
                 "launch_ms": per_launch_ms,
                 "launches": launches,
-                "algorithmic_bytes_per_launch": BYTES_PER_PIXEL_STEP * H * W * C,
+                "algorithmic_bytes_per_launch": int(BYTES_PER_PIXEL_STEP * H * W * C * its_per_launch),
+                "iterations_per_launch": its_per_launch,
                 # what actually limits the kernel when it is not HBM: vector-ALU busy fraction from the committed counters
                 # (SQ_ACTIVE_INST_VALU quad-cycles x 4 / (SIMDs x kernel cycles), profiles/): ~1 means VALU-issue bound
                 "valu": valu,

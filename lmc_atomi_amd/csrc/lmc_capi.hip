@@ -660,6 +660,7 @@ struct lmc_sampler {
   int64_t iteration = 0;
   uint64_t count = 0;
   float* x[2] = {nullptr, nullptr};
+  float* xspare = nullptr;    // third state array of the two-iterations-per-launch MYULA path (allocated at its first use)
   int cur = 0;
   double* s1 = nullptr;
   double* s2 = nullptr;
@@ -1014,7 +1015,7 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
 void lmc_sampler_destroy(lmc_sampler* s) {
   if (!s) return;
   DeviceGuard dg(s->device);
-  for (float* b : {s->zero_y, s->xhat, s->ydual, s->uw, s->uw2, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra, s->pxbuf,
+  for (float* b : {s->xspare, s->zero_y, s->xhat, s->ydual, s->uw, s->uw2, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra, s->pxbuf,
                    s->mx, s->xp, s->mxp, s->tvwarm[0], s->tvwarm[1], s->rtmp})
     if (b) (void)hipFree(b);
   if (s->robj) (void)hipFree(s->robj);
@@ -1236,6 +1237,8 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
   const bool graph_ok = !s->timing && (!overlap || (getenv("LMC_GRAPH") && atoi(getenv("LMC_GRAPH")) == 1)) && !noise_dev && s->noise_mode != LMC_NOISE_INJECTED && s->prob.ncvx_kind != LMC_NCVX_ME_TV &&
                         !s->tvwarm[0] && !s->rtmp && (!s->moments || s->thin == 1) && graph_wanted(s);
   bool graph_enabled = false;
+  const char* pair_env = getenv("LMC_ROWS_PAIR");
+  const int pair_mode = pair_env ? atoi(pair_env) : 1;
   for (int k = 0; k < n_iters; ++k) {
     if (graph_ok && s->plain_done && n_iters - k >= kGraphIters && (!s->moments || s->iteration >= s->burn_in) &&
         (s->kernel_name == "myula_step_rows_kernel" || s->kernel_name == "myula_step_block_kernel" || s->kernel_name == "myula_step_pipe_kernel")) {
@@ -1255,6 +1258,39 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     }
     if (graph_enabled) {   // plain launches after graph replays take their iteration word by value again: nothing to do (iter_dev is unused)
     }
+    // Two MYULA iterations per launch (lmc_step_rows_pair.hip) where that kernel covers the configuration and the launch is large enough for its
+    // long bands: x_{k+2} goes to a third array (neighbouring bands re-read x_k), x_{k+1} is stored only when the moment accumulators keep it.
+    // LMC_ROWS_PAIR: 0 = never, 2 = wherever covered (tests), default = where it pays (n_chains * H >= 2^17).  Read per call.
+    if (pair_mode && n_iters - k >= 2 && !noise_dev && !overlap && !graph_ok && !s->tvwarm[0] && !s->rtmp && s->prob.ncvx_kind == LMC_NCVX_NONE &&
+        (variant_of(s->prob) == 0 || variant_of(s->prob) == 6) && (pair_mode == 2 || (long long)s->C * s->prob.H >= (1 << 17))) {
+      lmc::StepArgs A = s->base;
+      A.x_in = s->x[s->cur];
+      A.iteration = (uint32_t)s->iteration;
+      A.noise = nullptr;
+      sanitize_pointers(A);
+      if (lmc::rows_pair_supported(A)) {
+        if (!s->xspare) {
+          HIP_TRY(hipMalloc(&s->xspare, sizeof(float) * per_iter));
+        }
+        auto kept = [&](int64_t it) { return s->moments && it >= s->burn_in && (it - s->burn_in) % s->thin == 0; };
+        const bool keep_mid = kept(s->iteration), keep_out = kept(s->iteration + 1);
+        A.x_out = s->xspare;
+        if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches], st));
+        HIP_TRY(lmc::launch_step_rows_pair(A, keep_mid ? s->x[s->cur ^ 1] : nullptr, st));
+        if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches + 1], st));
+        s->kernel_name = "myula_step_rows_pair_kernel";
+        s->plain_done = true;
+        if (keep_mid) { HIP_TRY(lmc::launch_moments(s->x[s->cur ^ 1], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
+        if (keep_out) { HIP_TRY(lmc::launch_moments(s->xspare, s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
+        std::swap(s->x[s->cur], s->xspare);        // x[cur] = x_{k+2}; the array that held x_k is the spare now
+        for (int i = 0; i < 2; ++i)                // captured graphs hold the old pointers
+          if (s->gexec[i]) { hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
+        s->iteration += 2;
+        ++s->last_launches;
+        ++k;
+        continue;
+      }
+    }
     lmc::StepArgs A = s->base;
     A.x_in = s->x[s->cur];
     A.x_out = s->x[s->cur ^ 1];
@@ -1271,7 +1307,7 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
       HIP_TRY(hipStreamWaitEvent(st, s->ev_mom[s->cur ^ 1], 0));
       s->mom_pending[s->cur ^ 1] = false;
     }
-    if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * k], st));
+    if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches], st));
     const char* kname = nullptr;
     hipError_t e;
     if (s->rtmp && A.prior_kind == LMC_PRIOR_TV_ISO) {   // early-exit TV prox first (exact pass-by-pass path), consumed as a ready-made prox
@@ -1293,7 +1329,7 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     HIP_TRY(e);
     if (kname) s->kernel_name = kname;
     s->plain_done = true;
-    if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * k + 1], st));
+    if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches + 1], st));
     s->cur ^= 1;
     if (s->moments && s->iteration >= s->burn_in && (s->iteration - s->burn_in) % s->thin == 0) {
       if (overlap && k + 1 < n_iters) {   // reduce x[cur] on the side stream while the next step kernel runs

@@ -58,6 +58,9 @@ hipError_t launch_step_block(const StepArgs& a, hipStream_t st);
 // barrier-free row streaming for a separable blur + closed-form prior (lmc_step_rows.hip)
 bool rows_supported(const StepArgs& a);
 hipError_t launch_step_rows(StepArgs a, hipStream_t st);
+// two MYULA iterations per launch (lmc_step_rows_pair.hip): x_out <- x_{k+2}, x_mid (may be NULL) <- x_{k+1}; three distinct arrays
+bool rows_pair_supported(const StepArgs& a);
+hipError_t launch_step_rows_pair(StepArgs a, float* x_mid, hipStream_t st);
 // taps re-centred for the full-width kernels: returns KT (5 or 7) and fills uc / vc, or 0 (lmc_step_rows.hip)
 int centred_blur_taps(const StepArgs& a, float* uc, float* vc);
 int centred_blur_taps(const BlurTaps& T, float* uc, float* vc);
