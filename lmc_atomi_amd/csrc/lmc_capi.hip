@@ -1239,6 +1239,8 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
   bool graph_enabled = false;
   const char* pair_env = getenv("LMC_ROWS_PAIR");
   const int pair_mode = pair_env ? atoi(pair_env) : 1;
+  const char* bp_env = getenv("LMC_BLOCK_PAIR");
+  const bool blockpair_on = !bp_env || atoi(bp_env) != 0;
   for (int k = 0; k < n_iters; ++k) {
     if (graph_ok && s->plain_done && n_iters - k >= kGraphIters && (!s->moments || s->iteration >= s->burn_in) &&
         (s->kernel_name == "myula_step_rows_kernel" || s->kernel_name == "myula_step_block_kernel" || s->kernel_name == "myula_step_pipe_kernel")) {
@@ -1285,6 +1287,36 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
         std::swap(s->x[s->cur], s->xspare);        // x[cur] = x_{k+2}; the array that held x_k is the spare now
         for (int i = 0; i < 2; ++i)                // captured graphs hold the old pointers
           if (s->gexec[i]) { hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
+        s->iteration += 2;
+        ++s->last_launches;
+        ++k;
+        continue;
+      }
+    }
+    // Two iterations per launch on the register-block kernel (Haar prior, stencil-free data term: BASELINE config 5): the update never leaves a
+    // thread's 8 x 8 block, so the second iteration runs on the block while it is on chip; x_{k+1} is written (in place, over x_k) only when the
+    // moment accumulators keep it.  LMC_BLOCK_PAIR=0 turns it off.  Same arithmetic, same noise: bit-identical to two launches.
+    if (blockpair_on && n_iters - k >= 2 && !noise_dev && !overlap && !graph_ok && !s->tvwarm[0] && !s->rtmp && s->prob.ncvx_kind == LMC_NCVX_NONE &&
+        (variant_of(s->prob) == 0 || variant_of(s->prob) == 5)) {
+      lmc::StepArgs A = s->base;
+      A.x_in = s->x[s->cur];
+      A.x_out = s->x[s->cur ^ 1];
+      A.iteration = (uint32_t)s->iteration;
+      A.noise = nullptr;
+      sanitize_pointers(A);
+      if (lmc::block_pair_supported(A)) {
+        auto kept = [&](int64_t it) { return s->moments && it >= s->burn_in && (it - s->burn_in) % s->thin == 0; };
+        const bool keep_mid = kept(s->iteration), keep_out = kept(s->iteration + 1);
+        A.fused_iters = 2;
+        A.x_mid = keep_mid ? s->x[s->cur] : nullptr;
+        if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches], st));
+        HIP_TRY(lmc::launch_step_block(A, st));
+        if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches + 1], st));
+        s->kernel_name = "myula_step_block_kernel(2 iterations)";
+        s->plain_done = true;
+        if (keep_mid) { HIP_TRY(lmc::launch_moments(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
+        s->cur ^= 1;
+        if (keep_out) { HIP_TRY(lmc::launch_moments(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
         s->iteration += 2;
         ++s->last_launches;
         ++k;

@@ -73,6 +73,10 @@ struct StepArgs {
   float g_scale;      // rows kernel only: the launch returns at once when *skip_flag != 0 (inner solver already converged)
   // prox computed by a preceding launch (Haar-l1 wavelet prior): px = prox_ext[c][i][j]; the kernel's own prior is NONE
   const float* prox_ext;
+  // block kernel only (Haar prior, no MC-TV term): fused_iters = 2 runs TWO iterations on the thread's 8 x 8 block before it goes back to memory
+  // (iterations `iteration` and `iteration + 1`; x_out <- x_{k+2}); x_mid (may be NULL, may be x_in itself: the update is block-local) <- x_{k+1}
+  int fused_iters;
+  float* x_mid;
 };
 
 constexpr uint32_t kPhiloxStream = 0x4C4D4301u;  // counter word 3 (noise field)

@@ -54,6 +54,7 @@ bool point_supported(const StepArgs& a);
 hipError_t launch_step_point(StepArgs a, hipStream_t st);
 // register-block kernel for stencil-free data terms and block-local proxes, Haar-l1 included (lmc_step_block.hip)
 bool block_supported(const StepArgs& a);
+bool block_pair_supported(const StepArgs& a);      // StepArgs::fused_iters = 2
 hipError_t launch_step_block(const StepArgs& a, hipStream_t st);
 // barrier-free row streaming for a separable blur + closed-form prior (lmc_step_rows.hip)
 bool rows_supported(const StepArgs& a);

@@ -22,8 +22,9 @@ __device__ __forceinline__ float soft_thr_b(float v, float thr) { return copysig
 // MC: the MC-TV term of L2_ncvx_tv, -lambda * A^T(A x / max(|A x|, gamma)) (algs.py:273-277), added to the gradient: a rolling window
 // of three 10-pixel rows (block columns -1 .. 8) around the output row -- the interior from the LDS copy, the halo from the
 // neighbouring blocks in memory (cache hits: those lines are being streamed by the neighbouring threads).
-template <int DATA, int PRIOR, bool MC = false>
+template <int DATA, int PRIOR, bool MC = false, int NF = 1>
 __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(const StepArgs P) {
+  static_assert(NF == 1 || (NF == 2 && PRIOR == LMC_PRIOR_HAAR_L1 && !MC), "two fused iterations: Haar prior without the MC-TV term");
   const int H = P.H, W = P.W;
   const int nbx = W >> 3;
   const uint32_t blocks_per_img = (uint32_t)nbx * (uint32_t)(H >> 3);
@@ -42,11 +43,24 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
   // 64-register copy of the block: 128 VGPRs less, 3-4 waves per SIMD instead of 2.
   float v[8][8];
   __shared__ float4 xs[PRIOR == LMC_PRIOR_HAAR_L1 ? 16 * 256 : 1];    // the thread's own copy of x: [row*2 + half][thread], 64 KB
+  // Two iterations per launch (P.fused_iters == 2; Haar prior without the MC-TV term: nothing of the update leaves the thread's block): the first
+  // iterate goes back into the slab instead of to memory (and to P.x_mid when the caller keeps it), the second pass reads the slab.
+  // (NF = 2: two straight-line copies of the pass -- a run-time loop around it cost 280 spilled VGPRs.)
+  float* __restrict__ mid = (NF == 2 && P.x_mid) ? P.x_mid + (size_t)chain * img + o0 : nullptr;
+  auto pass = [&](auto fitc) __attribute__((always_inline)) {
+  constexpr int fit = decltype(fitc)::value;
+  constexpr bool last_it = fit + 1 == NF;
   if (PRIOR == LMC_PRIOR_HAAR_L1) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const float4 lo = *reinterpret_cast<const float4*>(src + (size_t)r * W);
-      const float4 hi = *reinterpret_cast<const float4*>(src + (size_t)r * W + 4);
+      float4 lo, hi;
+      if (fit == 0) {
+        lo = *reinterpret_cast<const float4*>(src + (size_t)r * W);
+        hi = *reinterpret_cast<const float4*>(src + (size_t)r * W + 4);
+      } else {
+        lo = xs[(2 * r) * 256 + threadIdx.x];
+        hi = xs[(2 * r + 1) * 256 + threadIdx.x];
+      }
       v[r][0] = lo.x; v[r][1] = lo.y; v[r][2] = lo.z; v[r][3] = lo.w; v[r][4] = hi.x; v[r][5] = hi.y; v[r][6] = hi.z; v[r][7] = hi.w;
       xs[(2 * r) * 256 + threadIdx.x] = lo;
       xs[(2 * r + 1) * 256 + threadIdx.x] = hi;
@@ -104,7 +118,7 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
     if (P.noise_mode == LMC_NOISE_PHILOX) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        quad_normals(P.key0, P.key1, P.iteration + (P.iter_dev ? *P.iter_dev : 0u), P.chain_offset + chain, (uint32_t)(by * 2 + q) * (uint32_t)W + (uint32_t)(bx * 8 + j), nz[j]);
+        quad_normals(P.key0, P.key1, P.iteration + (P.iter_dev ? *P.iter_dev : 0u) + (uint32_t)fit, P.chain_offset + chain, (uint32_t)(by * 2 + q) * (uint32_t)W + (uint32_t)(bx * 8 + j), nz[j]);
         if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two Philox calls in flight, not eight: their temporaries decide the occupancy
       }
     }
@@ -156,10 +170,28 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
                                                       gj > 0, gj + 1 < W, P.ncvx_gamma), o[j]);
         }
       }
-      *reinterpret_cast<float4*>(dst + (size_t)r * W) = make_float4(o[0], o[1], o[2], o[3]);
-      *reinterpret_cast<float4*>(dst + (size_t)r * W + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      if (last_it) {
+        *reinterpret_cast<float4*>(dst + (size_t)r * W) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(dst + (size_t)r * W + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      } else {        // row r of the slab has been read (above): it takes the new iterate
+        xs[(2 * r) * 256 + threadIdx.x] = make_float4(o[0], o[1], o[2], o[3]);
+        xs[(2 * r + 1) * 256 + threadIdx.x] = make_float4(o[4], o[5], o[6], o[7]);
+        if (mid) {
+          *reinterpret_cast<float4*>(mid + (size_t)r * W) = make_float4(o[0], o[1], o[2], o[3]);
+          *reinterpret_cast<float4*>(mid + (size_t)r * W + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+      }
     }
   }
+  };   // pass
+  pass(std::integral_constant<int, 0>{});
+  if constexpr (NF == 2) pass(std::integral_constant<int, 1>{});
+}
+
+// two iterations per launch: the block-local combination only (Haar prior, stencil-free data term, no MC-TV term), Philox or no noise
+bool block_pair_supported(const StepArgs& a) {
+  return block_supported(a) && a.prior_kind == LMC_PRIOR_HAAR_L1 && a.ncvx_kind == LMC_NCVX_NONE &&
+         (a.noise_mode == LMC_NOISE_PHILOX || a.noise_mode == LMC_NOISE_NONE);
 }
 
 bool block_supported(const StepArgs& a) {
@@ -179,6 +211,7 @@ static void launch_block_data(const StepArgs& a, int nblk, hipStream_t st) {
     case LMC_PRIOR_L1: hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_L1>), dim3(nblk), dim3(256), 0, st, a); break;
     case LMC_PRIOR_HAAR_L1:
       if (a.ncvx_kind == LMC_NCVX_MC_TV) hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_HAAR_L1, true>), dim3(nblk), dim3(256), 0, st, a);
+      else if (a.fused_iters == 2) hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_HAAR_L1, false, 2>), dim3(nblk), dim3(256), 0, st, a);
       else hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_HAAR_L1>), dim3(nblk), dim3(256), 0, st, a);
       break;
     default: hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_NONE>), dim3(nblk), dim3(256), 0, st, a); break;
@@ -187,6 +220,7 @@ static void launch_block_data(const StepArgs& a, int nblk, hipStream_t st) {
 
 hipError_t launch_step_block(const StepArgs& a, hipStream_t st) {
   if (!block_supported(a)) return hipErrorInvalidConfiguration;
+  if (a.fused_iters == 2 && !block_pair_supported(a)) return hipErrorInvalidConfiguration;
   const size_t nb = (size_t)(a.H >> 3) * (a.W >> 3) * (size_t)a.C;
   const size_t nblk = (nb + 255) / 256;
   if (nblk > 0x7fffffffu) return hipErrorInvalidConfiguration;

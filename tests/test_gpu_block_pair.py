@@ -1,0 +1,52 @@
+"""Two MYULA iterations per launch on the register-block kernel (stencil-free data term + Haar-l1 prior: BASELINE config 5): the update is local
+to a thread's 8 x 8 block, so two launches and one fused launch are the same arithmetic in the same order -- bit-identical states and moment
+accumulators, odd counts, burn-in / thinning, x_{k+1} written in place when it is kept."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+    assert torch.cuda.is_available()
+    import lmc_atomi_amd as la
+    return la
+
+
+@pytest.mark.parametrize("shape,C,nit,data", [((64, 128), 3, 5, "mask"), ((512, 512), 2, 4, "mask"), ((40, 72), 5, 7, "identity"), ((8, 8), 1, 2, "mask")])
+@pytest.mark.parametrize("moments", [True, False])
+def test_block_pairs_are_bit_identical_to_single_launches(la, shape, C, nit, data, moments, monkeypatch):
+    monkeypatch.setenv("LMC_MOMENTS_OVERLAP", "0")
+    rng = np.random.default_rng(shape[1])
+    img = np.zeros(shape); img[shape[0] // 4:shape[0] // 2, shape[1] // 4:3 * shape[1] // 4] = 180.0
+    sig = 0.75
+    if data == "mask":
+        mask = (rng.uniform(size=shape) < 0.6).astype(np.float64)
+        pf = lambda: la.L2(Op=la.Diagonal(mask, dims=shape), b=mask * (img + rng.normal(0, sig, shape)), sigma=1 / sig ** 2)
+    else:
+        yb = img + rng.normal(0, sig, shape)
+        pf = lambda: la.L2(b=yb, sigma=1 / sig ** 2, dims=shape)
+    f = pf()
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LMC_BLOCK_PAIR", mode)
+        smp = la.MYULASampler(f, la.WaveletL1(shape, sigma=0.3), shape, n_chains=C, tau=0.1125, gamma=0.5625, seed=31, chain_offset=2,
+                              moments=moments, burn_in=1, thin=2 if nit > 4 else 1)
+        smp.set_state(img)
+        smp.step(nit)
+        name = smp.kernel_name
+        extra = ()
+        if moments:
+            m1, m2, cnt = smp.moments()
+            extra = (m1.cpu().numpy(), m2.cpu().numpy(), cnt)
+        outs[mode] = (smp.get_state().cpu().numpy(), name) + extra
+        smp.close()
+    assert "2 iterations" in outs["1"][1] or nit % 2 == 1, outs["1"][1]
+    assert "2 iterations" not in outs["0"][1]
+    np.testing.assert_array_equal(outs["1"][0], outs["0"][0])
+    if moments:
+        assert outs["1"][4] == outs["0"][4]
+        np.testing.assert_array_equal(outs["1"][2], outs["0"][2])
+        np.testing.assert_array_equal(outs["1"][3], outs["0"][3])
