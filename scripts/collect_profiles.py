@@ -10,6 +10,7 @@ WORK = {   # tag -> (bench.py workload key, sampler kernel name)
     "rowspair": ({"H": 512, "W": 512, "C": 1024, "prior": "l2", "data": "blur", "tv_iters": 10, "ncvx": "none"}, "myula_step_rows_pair_kernel"),
     "c2": ({"H": 256, "W": 256, "C": 128, "prior": "l2", "data": "blur", "tv_iters": 10, "ncvx": "none"}, "myula_step_rows_kernel"),
     "block": ({"H": 512, "W": 512, "C": 1024, "prior": "haar", "data": "mask", "tv_iters": 10, "ncvx": "none"}, "myula_step_block_kernel"),
+    "blockpair": ({"H": 512, "W": 512, "C": 1024, "prior": "haar", "data": "mask", "tv_iters": 10, "ncvx": "none"}, "myula_step_block_kernel(2 iterations)"),
     "warm1": ({"H": 512, "W": 512, "C": 1024, "prior": "tv", "data": "blur", "tv_iters": 1, "ncvx": "none", "tv_warm": True}, "myula_step_pipe_kernel(warm)"),
     "warm2": ({"H": 512, "W": 512, "C": 1024, "prior": "tv", "data": "blur", "tv_iters": 2, "ncvx": "none", "tv_warm": True}, "myula_step_pipe_kernel(warm)"),
     "warm3": ({"H": 512, "W": 512, "C": 1024, "prior": "tv", "data": "blur", "tv_iters": 3, "ncvx": "none", "tv_warm": True}, "myula_step_pipe_kernel(warm)"),
@@ -36,7 +37,7 @@ for d in sorted(os.listdir(os.path.join(ROOT, "gpurun_out"))):
             e = {"kernel": kname, "kernel_instantiation": k, "workload": work, "source": f"profiles/{rnd}_{tag}_rocprofv3_summary.txt",
                  "FETCH_SIZE_KiB": ent["counters"]["FETCH_SIZE"], "WRITE_SIZE_KiB": ent["counters"]["WRITE_SIZE"],
                  "traffic_bytes_per_launch": ent["traffic_bytes_per_launch"],
-                 "algorithmic_bytes_per_launch": 8 * work["H"] * work["W"] * work["C"] * (2 if "pair" in kname else 1),   # a pair launch = two iterations
+                 "algorithmic_bytes_per_launch": 8 * work["H"] * work["W"] * work["C"] * (2 if ("pair" in kname or "2 iterations" in kname) else 1),   # a pair launch = two iterations
                  "trace_avg_ns": ent.get("avg_ns"), "trace_calls": ent.get("calls"), "valu": ent.get("valu")}
             entries.append(e)
 json.dump({"note": "per-launch counters of the step kernels from rocprofv3 (scripts/profile.sh: 60-step kernel trace; PMC in separate passes). "

@@ -9,9 +9,11 @@ if [ $part = a ]; then
   bash scripts/profile.sh r02_rowspair --prior l2 > /dev/null 2>&1 && echo rowspair done
   bash scripts/profile.sh r02_rowspairnm --prior l2 --no-moments > /dev/null 2>&1 && echo rowspairnm done
   bash scripts/profile.sh r02_c2 --prior l2 --size 256 --chains 128 > /dev/null 2>&1 && echo c2 done
-  bash scripts/profile.sh r02_block --prior haar --data mask > /dev/null 2>&1 && echo block done
+  LMC_BLOCK_PAIR=0 bash scripts/profile.sh r02_block --prior haar --data mask > /dev/null 2>&1 && echo block done
+  bash scripts/profile.sh r02_blockpair --prior haar --data mask > /dev/null 2>&1 && echo blockpair done
+  bash scripts/profile.sh r02_blockpairnm --prior haar --data mask --no-moments > /dev/null 2>&1 && echo blockpairnm done
   bash scripts/profile.sh r02_ulpda --alg ulpda > /dev/null 2>&1 && echo ulpda done
-  tags="pipe rows rowspair rowspairnm c2 block ulpda"
+  tags="pipe rows rowspair rowspairnm c2 block blockpair blockpairnm ulpda"
 else
   for k in 1 2 3; do bash scripts/profile.sh r02_warm$k --tv-warm --tv-iters $k > /dev/null 2>&1 && echo warm$k done; done
   bash scripts/profile.sh r02_wide877tv --size 667 --width 877 --chains 512 > /dev/null 2>&1 && echo wide877tv done
