@@ -641,6 +641,9 @@ struct lmc_sampler {
   int gfirst = 0, cg_niter = 0, warm = 1;
   const float* z = nullptr;
   float* xhat = nullptr; float* ydual = nullptr; float* uw = nullptr; float* rhs = nullptr;
+  float* ydual2 = nullptr;    // ULPDA: the dual array the fused dual + right-hand-side pass writes (swapped with ydual after it)
+  bool rhs_ready = false;     // ULPDA: s->rhs already holds the right-hand side of the NEXT iteration for (rhs_tau, rhs_ts), formed by that pass
+  float rhs_tau = 0.f, rhs_ts = 0.f;
   float* uw2 = nullptr;       // ULPDA: the other home of the implicit-step solution (two Chebyshev iterations per launch deliver it there)
   float* cr = nullptr; float* cp = nullptr; float* cq = nullptr; float* ctmp = nullptr; float* xi = nullptr;
   float* htb = nullptr; double* scal = nullptr; float* zero_y = nullptr;
@@ -1015,7 +1018,7 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
 void lmc_sampler_destroy(lmc_sampler* s) {
   if (!s) return;
   DeviceGuard dg(s->device);
-  for (float* b : {s->xspare, s->zero_y, s->xhat, s->ydual, s->uw, s->uw2, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra, s->pxbuf,
+  for (float* b : {s->ydual2, s->xspare, s->zero_y, s->xhat, s->ydual, s->uw, s->uw2, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra, s->pxbuf,
                    s->mx, s->xp, s->mxp, s->tvwarm[0], s->tvwarm[1], s->rtmp})
     if (b) (void)hipFree(b);
   if (s->robj) (void)hipFree(s->robj);
@@ -1499,6 +1502,14 @@ static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, h
   static const bool fuse_env = [] { const char* e = getenv("LMC_ULPDA_FUSE"); return e && atoi(e) != 0; }();
   const bool fuse_fd = fuse_env && !s->gfirst && s->x[1] && lmc::ulpda_finish_dual_supported(H, W);
   bool used_pairs = false;
+  // LMC_ULPDA_DUAL_RHS=1 (opt-in): the dual update fused with the next iteration's right-hand side (ulpda_dual_rhs4_kernel: 28 instead of 36 B per
+  // pixel, bit-identical -- tests/test_gpu_ulpda.py).  Measured at 512 x 512 x 1024 on one box, alternating: 5.61 / 5.61 ms per iteration fused
+  // against 5.57 / 5.66 ms with the two passes -- the neighbour recomputation costs what the 8 B save; left off.  Inside one call only
+  // (k + 1 < n_iters): between calls the caller may change the steps, the state or the dual.
+  const char* dr_env = getenv("LMC_ULPDA_DUAL_RHS");
+  const bool fuse_dr = dr_env && atoi(dr_env) != 0 && !s->gfirst && !fuse_fd && s->ydual2 && s->prob.ncvx_kind == LMC_NCVX_NONE &&
+                       lmc::ulpda_dual_rhs_supported(H, W);
+  s->rhs_ready = false;
   for (int k = 0; k < n_iters; ++k) {
     float* x = s->x[s->cur];
     const float ts = s->tau * s->prob.sigma_f;
@@ -1513,8 +1524,11 @@ static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, h
       int rc = me_tv_prox(s->prob, s->ctmp, s->extra, C, s->tvstate[0], s->tvstate[1], st);
       if (rc) return rc;
       HIP_TRY(lmc::ulpda_me_rhs(s->ctmp, s->extra, s->htb, s->rhs, C, H, W, s->tau * s->prob.ncvx_lambda / s->prob.ncvx_gamma, ts, st));
+    } else if (s->rhs_ready && s->rhs_tau == s->tau && s->rhs_ts == ts) {
+      // formed together with the previous iteration's dual update (fuse_dr below)
     } else
     HIP_TRY(lmc::ulpda_rhs(x, s->ydual, s->z, s->prob.data_kind == LMC_DATA_BLUR ? s->htb : nullptr, s->rhs, C, H, W, s->tau, ts, st));
+    s->rhs_ready = false;
     const float* u = s->rhs;
     if (s->prob.data_kind == LMC_DATA_BLUR) {
       if (!s->warm) HIP_TRY(hipMemsetAsync(s->uw, 0, sizeof(float) * per_iter, st));
@@ -1546,8 +1560,18 @@ static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, h
       }
       HIP_TRY(lmc::ulpda_finish(x, s->xhat, u, xi, C, H, W, std::sqrt(2.f * s->tau), s->theta, st));
     }
-    if (!s->gfirst && !fuse_fd)  // (algs.py:448)
-      HIP_TRY(lmc::ulpda_dual_update(s->xhat, s->ydual, C, H, W, s->mu, s->prob.prior_sigma, iso, st));
+    if (!s->gfirst && !fuse_fd) {  // (algs.py:448)
+      if (fuse_dr && k + 1 < n_iters) {
+        // ... fused with the right-hand side of the next iteration (same tau unless lmc_sampler_set_steps intervenes: then it is formed again):
+        // 28 instead of 20 + 16 B per pixel, bit-identical to the two passes
+        HIP_TRY(lmc::ulpda_dual_rhs(s->xhat, s->ydual, s->ydual2, x, s->z, s->prob.data_kind == LMC_DATA_BLUR ? s->htb : nullptr, s->rhs, C, H, W, s->mu,
+                                    s->prob.prior_sigma, iso, s->tau, ts, st));
+        std::swap(s->ydual, s->ydual2);
+        s->rhs_ready = true; s->rhs_tau = s->tau; s->rhs_ts = ts;
+      } else {
+        HIP_TRY(lmc::ulpda_dual_update(s->xhat, s->ydual, C, H, W, s->mu, s->prob.prior_sigma, iso, st));
+      }
+    }
     if (s->moments && s->iteration >= s->burn_in && (s->iteration - s->burn_in) % s->thin == 0) {
       HIP_TRY(lmc::launch_moments(x, s->C, H, W, s->s1, s->s2, st));
       s->count += (uint64_t)s->C;
@@ -1597,6 +1621,7 @@ int lmc_ulpda_create(const lmc_ulpda_config* cfg, lmc_sampler** out) {
   hipError_t e = hipSuccess;
   auto alloc = [&](float** p, size_t count) { if (e == hipSuccess) e = hipMalloc(p, sizeof(float) * count); if (e == hipSuccess) e = hipMemset(*p, 0, sizeof(float) * count); };
   alloc(&s->x[0], n); alloc(&s->xhat, n); alloc(&s->ydual, 2 * n); alloc(&s->uw, n); alloc(&s->rhs, n);
+  if (!s->gfirst && s->prob.ncvx_kind == LMC_NCVX_NONE && lmc::ulpda_dual_rhs_supported(s->prob.H, s->prob.W)) alloc(&s->ydual2, 2 * n);
   if (!s->gfirst && lmc::ulpda_finish_dual_supported(s->prob.H, s->prob.W) && getenv("LMC_ULPDA_FUSE") && atoi(getenv("LMC_ULPDA_FUSE")))
     alloc(&s->x[1], n);     // ping-pong target of the fused finish + dual pass (opt-in, see ulpda_step)
   if (s->noise_mode == LMC_NOISE_PHILOX) alloc(&s->xi, n);

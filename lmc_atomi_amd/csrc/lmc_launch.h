@@ -102,6 +102,9 @@ hipError_t cg_init(const float* rhs, const float* q, float* r, float* p, int64_t
 hipError_t cg_update(float* u, float* r, const float* p, const float* q, int64_t C, size_t img, const double* rs, const double* pq,
                      double* rs_new, const int* done, hipStream_t st);
 hipError_t cg_dir(float* p, const float* r, int64_t C, size_t img, double* rs, const double* rs_new, const int* done, hipStream_t st);
+bool ulpda_dual_rhs_supported(int H, int W);
+hipError_t ulpda_dual_rhs(const float* xhat, const float* y_in, float* y_out, const float* x, const float* z, const float* htb, float* rhs, int64_t C,
+                          int H, int W, float mu, float radius, int iso, float tau, float ts, hipStream_t st);
 hipError_t cheb_count(int64_t C, const double* stat, double inv_alpha2, double tol, double inv_log_inv_c, int kmax, int* count,
                       hipStream_t st);
 hipError_t cg_check(int64_t C, const double* rsv, const double* b2, double tol2, int* done, hipStream_t st);
