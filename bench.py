@@ -18,6 +18,8 @@ ranks) is run R = 3 times back to back and the MEDIAN region is reported (`repea
 is the HIP-event average over the launches of that median region, on the launch stream.  `roofline` carries the spec peak, the
 bandwidth a state-shaped copy measures on this device in this process (`peak_measured`), and a `valu` block (vector-ALU busy
 fraction of the same kernel from the committed rocprofv3 counters): at K = 10 the update is bound by VALU issue, not by HBM.
+Where a launch advances every chain by TWO iterations (closed-form priors and the Haar prior: `--prior l2|l1|haar`; not the headline),
+`roofline.iterations_per_launch` = 2 and `algorithmic_bytes_per_launch` counts both (8 B per pixel per iteration).
 """
 import argparse
 import json
