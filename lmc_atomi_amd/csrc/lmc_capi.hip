@@ -1309,20 +1309,23 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
       sanitize_pointers(A);
       if (lmc::block_pair_supported(A)) {
         auto kept = [&](int64_t it) { return s->moments && it >= s->burn_in && (it - s->burn_in) % s->thin == 0; };
-        const bool keep_mid = kept(s->iteration), keep_out = kept(s->iteration + 1);
-        A.fused_iters = 2;
+        // four iterations on chip when none of the three iterates in between is kept (moments off, burn-in, thinning by >= 4)
+        const bool four = n_iters - k >= 4 && !kept(s->iteration) && !kept(s->iteration + 1) && !kept(s->iteration + 2);
+        const int nf = four ? 4 : 2;
+        const bool keep_mid = !four && kept(s->iteration), keep_out = kept(s->iteration + nf - 1);
+        A.fused_iters = nf;
         A.x_mid = keep_mid ? s->x[s->cur] : nullptr;
         if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches], st));
         HIP_TRY(lmc::launch_step_block(A, st));
         if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches + 1], st));
-        s->kernel_name = "myula_step_block_kernel(2 iterations)";
+        s->kernel_name = four ? "myula_step_block_kernel(4 iterations)" : "myula_step_block_kernel(2 iterations)";
         s->plain_done = true;
         if (keep_mid) { HIP_TRY(lmc::launch_moments(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
         s->cur ^= 1;
         if (keep_out) { HIP_TRY(lmc::launch_moments(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
-        s->iteration += 2;
+        s->iteration += nf;
         ++s->last_launches;
-        ++k;
+        k += nf - 1;
         continue;
       }
     }

@@ -24,7 +24,7 @@ __device__ __forceinline__ float soft_thr_b(float v, float thr) { return copysig
 // neighbouring blocks in memory (cache hits: those lines are being streamed by the neighbouring threads).
 template <int DATA, int PRIOR, bool MC = false, int NF = 1>
 __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(const StepArgs P) {
-  static_assert(NF == 1 || (NF == 2 && PRIOR == LMC_PRIOR_HAAR_L1 && !MC), "two fused iterations: Haar prior without the MC-TV term");
+  static_assert(NF == 1 || ((NF == 2 || NF == 4) && PRIOR == LMC_PRIOR_HAAR_L1 && !MC), "fused iterations: Haar prior without the MC-TV term");
   const int H = P.H, W = P.W;
   const int nbx = W >> 3;
   const uint32_t blocks_per_img = (uint32_t)nbx * (uint32_t)(H >> 3);
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
   // Two iterations per launch (P.fused_iters == 2; Haar prior without the MC-TV term: nothing of the update leaves the thread's block): the first
   // iterate goes back into the slab instead of to memory (and to P.x_mid when the caller keeps it), the second pass reads the slab.
   // (NF = 2: two straight-line copies of the pass -- a run-time loop around it cost 280 spilled VGPRs.)
-  float* __restrict__ mid = (NF == 2 && P.x_mid) ? P.x_mid + (size_t)chain * img + o0 : nullptr;
+  float* __restrict__ mid = (NF == 2 && P.x_mid) ? P.x_mid + (size_t)chain * img + o0 : nullptr;      // NF = 4: no iterate in between is kept
   auto pass = [&](auto fitc) __attribute__((always_inline)) {
   constexpr int fit = decltype(fitc)::value;
   constexpr bool last_it = fit + 1 == NF;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
       } else {        // row r of the slab has been read (above): it takes the new iterate
         xs[(2 * r) * 256 + threadIdx.x] = make_float4(o[0], o[1], o[2], o[3]);
         xs[(2 * r + 1) * 256 + threadIdx.x] = make_float4(o[4], o[5], o[6], o[7]);
-        if (mid) {
+        if (fit == 0 && mid) {
           *reinterpret_cast<float4*>(mid + (size_t)r * W) = make_float4(o[0], o[1], o[2], o[3]);
           *reinterpret_cast<float4*>(mid + (size_t)r * W + 4) = make_float4(o[4], o[5], o[6], o[7]);
         }
@@ -184,8 +184,7 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
     }
   }
   };   // pass
-  pass(std::integral_constant<int, 0>{});
-  if constexpr (NF == 2) pass(std::integral_constant<int, 1>{});
+  static_for<0, NF>([&](auto fc) { pass(fc); });
 }
 
 // two iterations per launch: the block-local combination only (Haar prior, stencil-free data term, no MC-TV term), Philox or no noise
@@ -212,6 +211,7 @@ static void launch_block_data(const StepArgs& a, int nblk, hipStream_t st) {
     case LMC_PRIOR_HAAR_L1:
       if (a.ncvx_kind == LMC_NCVX_MC_TV) hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_HAAR_L1, true>), dim3(nblk), dim3(256), 0, st, a);
       else if (a.fused_iters == 2) hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_HAAR_L1, false, 2>), dim3(nblk), dim3(256), 0, st, a);
+      else if (a.fused_iters == 4) hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_HAAR_L1, false, 4>), dim3(nblk), dim3(256), 0, st, a);
       else hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_HAAR_L1>), dim3(nblk), dim3(256), 0, st, a);
       break;
     default: hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_NONE>), dim3(nblk), dim3(256), 0, st, a); break;
@@ -220,7 +220,8 @@ static void launch_block_data(const StepArgs& a, int nblk, hipStream_t st) {
 
 hipError_t launch_step_block(const StepArgs& a, hipStream_t st) {
   if (!block_supported(a)) return hipErrorInvalidConfiguration;
-  if (a.fused_iters == 2 && !block_pair_supported(a)) return hipErrorInvalidConfiguration;
+  if (a.fused_iters != 0 && a.fused_iters != 1 && a.fused_iters != 2 && a.fused_iters != 4) return hipErrorInvalidConfiguration;
+  if (a.fused_iters >= 2 && (!block_pair_supported(a) || (a.fused_iters == 4 && a.x_mid))) return hipErrorInvalidConfiguration;
   const size_t nb = (size_t)(a.H >> 3) * (a.W >> 3) * (size_t)a.C;
   const size_t nblk = (nb + 255) / 256;
   if (nblk > 0x7fffffffu) return hipErrorInvalidConfiguration;
