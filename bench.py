@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.
 BYTES_PER_PIXEL_STEP = 8       # algorithmic: one fp32 read of x_k + one fp32 write of x_{k+1}
 
 
-def synth_problem(H, W, sigma, seed=0, blur="box"):
+def synth_problem(H, W, sigma, seed=0, blur="box", blur_k=5):
     """Piecewise-constant + ramp ground truth in [0,255] from default_rng(1234); y = H u + N(0, sigma^2)
     with noise from default_rng(seed) (mirrors prox_lmc_deconv.py:53-59).  Host-side setup, not timed."""
     rng = np.random.default_rng(1234)
@@ -55,10 +55,12 @@ def synth_problem(H, W, sigma, seed=0, blur="box"):
     # blur with scipy (setup only): zero-padded 'same' convolution, centred 5x5
     import scipy.signal
     y = scipy.signal.convolve2d(u, h, mode="same") + np.random.default_rng(seed).normal(0, sigma, (H, W))
+    if blur_k != 5:     # the reference's mismatched models: the observation is always made with the 5x5 box, the MODEL blurs with k x k
+        h = np.ones((blur_k, blur_k)) / float(blur_k * blur_k)     # (prox_lmc_deconv.py:61-69, 102-103)
     return u, h, y
 
 
-def cpu_baseline(H, W, h, y, sigma, prior, label, mask=None, chains=4, iters=20):
+def cpu_baseline(H, W, h, y, sigma, prior, label, mask=None, chains=4, iters=20, offset=(2, 2)):
     """The oracle on a bounded sample of the same workload, timed on this host: the C restatement
     (oracle/lmc_oracle_c.c, float64, OpenMP over chains, PCG64 noise from numpy) on up to 16 cores -- the GPU box's CPU
     share for one GPU -- is the reported value; the numpy restatement (the one pinned by the reference's own outputs;
@@ -68,7 +70,7 @@ def cpu_baseline(H, W, h, y, sigma, prior, label, mask=None, chains=4, iters=20)
     from oracle import lmc_oracle_c as OC
     OC.build()
     gamma, tau = sigma ** 2, 0.2 * sigma ** 2
-    hh, off = (None, None) if mask is not None else (h, (2, 2))
+    hh, off = (None, None) if mask is not None else (h, offset)
 
     def run(step, n_chains, n_it, **kw):
         rng = np.random.default_rng(0)
@@ -110,6 +112,9 @@ def main():
     ap.add_argument("--no-moments", action="store_true")
     ap.add_argument("--data", default="blur", choices=["blur", "identity", "mask"], help="data term (experiments)")
     ap.add_argument("--blur", default="box", choices=["box", "gaussian"], help="5x5 blur: the reference's uniform box or a Gaussian (s=1)")
+    ap.add_argument("--blur-k", type=int, default=5, choices=[5, 6, 7],
+                    help="size of the model's uniform box blur, offset (k//2, k//2): the reference's H5 / H6 / H7 (prox_lmc_deconv.py:55-69)")
+    ap.add_argument("--mask-p", type=float, default=0.5, help="--data mask: fraction of observed pixels (SURVEY 8(d) C5: Bernoulli(0.5), default_rng(7))")
     ap.add_argument("--ncvx", default="none", choices=["none", "mc", "me"],
                     help="add the L2_ncvx_tv Moreau-difference term (lamda=0.3, gamma=15; SURVEY 8(d) C5)")
     ap.add_argument("--ncvx-iters", type=int, default=None, help="inner TV-prox iterations of the ME-TV term (default: --tv-iters; the reference uses niter_l2 = 50)")
@@ -131,7 +136,8 @@ def main():
     if args.config == 2:
         args.size, args.chains, args.prior = 256, 128, "l2"
     elif args.config == 5:
-        args.size, args.chains, args.prior, args.data = 512, 512, "haar", "mask"
+        # Bernoulli(0.5) mask + Haar-l1 prox + the L2_ncvx_tv Moreau-difference (MC-TV) term that makes it non-log-concave
+        args.size, args.chains, args.prior, args.data, args.ncvx = 512, 512, "haar", "mask", "mc"
 
     # stdout carries ONE JSON line and nothing else: libraries that print banners on fd 1 (RCCL's version block at communicator set-up)
     # are sent to stderr for the whole run; the line itself goes to the saved descriptor
@@ -177,11 +183,12 @@ def main():
     C = args.chains
     sigma, tau_reg = 0.75, 0.3                       # prox_lmc_deconv.py:40 defaults
     gamma, tau = sigma ** 2, 0.2 * sigma ** 2 * args.tau_scale        # prox_lmc_deconv.py:92-94
-    u, h, y = synth_problem(H, W, sigma, blur=args.blur)
+    u, h, y = synth_problem(H, W, sigma, blur=args.blur, blur_k=args.blur_k)
+    boff = (args.blur_k // 2, args.blur_k // 2)
     if args.data == "blur":
-        pf = la.L2(Op=la.Convolve2D((H, W), h, offset=(2, 2)), b=y, sigma=1 / sigma ** 2)
-    elif args.data == "mask":                        # inpainting: 60 % of the pixels observed
-        m = (np.random.default_rng(7).uniform(size=(H, W)) < 0.6).astype(np.float32)
+        pf = la.L2(Op=la.Convolve2D((H, W), h, offset=boff), b=y, sigma=1 / sigma ** 2)
+    elif args.data == "mask":                        # inpainting: a Bernoulli(mask_p) mask from default_rng(7)
+        m = (np.random.default_rng(7).uniform(size=(H, W)) < args.mask_p).astype(np.float32)
         pf = la.L2(Op=la.Diagonal(m, dims=(H, W)), b=m * u, sigma=1 / sigma ** 2, dims=(H, W))
     else:
         pf = la.L2(b=y, sigma=1 / sigma ** 2, dims=(H, W))
@@ -259,6 +266,8 @@ def main():
         # only quoted when the profile is of this kernel on this workload
         traffic, valu = None, None
         want = {"H": H, "W": W, "C": C, "prior": args.prior, "data": args.data, "tv_iters": args.tv_iters, "ncvx": args.ncvx}
+        if args.blur_k != 5:
+            want["blur_k"] = args.blur_k
         if args.tv_warm:
             want["tv_warm"] = True
         if args.tv_lagged:
@@ -300,7 +309,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{H}x{W} MYULA " + {"blur": f"deblur (5x5 {'uniform box' if args.blur == 'box' else 'Gaussian s=1'} blur, sigma={sigma})", "mask": "inpainting (60 % mask)",
+                "workload": f"{H}x{W} MYULA " + {"blur": f"deblur ({args.blur_k}x{args.blur_k} {'uniform box' if args.blur == 'box' else 'Gaussian s=1'} blur, sigma={sigma})", "mask": f"inpainting (Bernoulli({args.mask_p}) mask)",
                                                    "identity": "denoise"}[args.data] + f" + {prior_desc}" + ({"none": "", "mc": " - MC-TV term (lamda=0.3, gamma=15)", "me": f" - ME-TV term (lamda=0.3, gamma=15, {args.ncvx_iters or args.tv_iters} inner its)"}[args.ncvx]) + ", "
                             f"{C} chains/GPU x {world} GPU, Philox noise, x0=0, "
                             + ("no moments" if args.no_moments else f"posterior moments every {args.thin} it"),
@@ -344,12 +353,12 @@ def main():
             if args.data == "blur":
                 oy, omask, oh = y, None, h
             elif args.data == "mask":
-                omask = (np.random.default_rng(7).uniform(size=(H, W)) < 0.6).astype(np.float64)
+                omask = (np.random.default_rng(7).uniform(size=(H, W)) < args.mask_p).astype(np.float64)
                 oy, oh = omask * u, None
             else:
                 oy, omask, oh = y, None, None
             label = f"MYULA {args.data} + {args.prior}" + (f"(K={args.tv_iters})" if args.prior == "tv" else "")
-            out["cpu_baseline"] = cpu_baseline(H, W, oh, oy, sigma, oprior, label, mask=omask, chains=args.cpu_chains, iters=args.cpu_iters)
+            out["cpu_baseline"] = cpu_baseline(H, W, oh, oy, sigma, oprior, label, mask=omask, chains=args.cpu_chains, iters=args.cpu_iters, offset=boff)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     smp.close()
