@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--tv-warm", action="store_true",
                     help="warm-dual TV (SURVEY 8(d) C3 variant; build extension): carry the TV dual between MYULA iterations, "
                          "--tv-iters in {1, 2, 3} per iteration (+16 B/px of HBM traffic, quoted as `actual_bytes_per_launch`)")
+    ap.add_argument("--tv-rtol", type=float, default=0.0,
+                    help="pyproximal.TV's per-image early exit (1e-4 = the reference as configured, prox_lmc_deconv.py:122; 0 = always --tv-iters passes, the headline)")
+    ap.add_argument("--ncvx-rtol", type=float, default=0.0, help="--ncvx me: early exit of the inner TV prox (1e-4 = the class's own default, algs.py:130,169)")
     ap.add_argument("--tv-lagged", action="store_true", help="TV prox after tv_iters - 1 dual updates (lmc_problem.tv_lagged_output)")
     ap.add_argument("--no-hbm-probe", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,8 +197,8 @@ def main():
         pf = la.L2(b=y, sigma=1 / sigma ** 2, dims=(H, W))
     if args.ncvx != "none":                          # prox_lmc_deconv.py:106-113 (niter of the inner TV prox = --tv-iters)
         pf = la.L2_ncvx_tv(dims=(H, W), Op=pf.Op, Op2=la.Gradient((H, W)) if args.ncvx == "mc" else None, b=pf.b, sigma=1 / sigma ** 2,
-                           lamda=tau_reg, gamma=15.0, isotropic=True, niter=args.ncvx_iters or args.tv_iters)
-    pg = {"tv": lambda: la.TV((H, W), sigma=tau_reg, niter=args.tv_iters, warm=args.tv_warm, lagged_output=args.tv_lagged), "l2": lambda: la.L2(sigma=0.05),
+                           lamda=tau_reg, gamma=15.0, isotropic=True, niter=args.ncvx_iters or args.tv_iters, rtol=args.ncvx_rtol)
+    pg = {"tv": lambda: la.TV((H, W), sigma=tau_reg, niter=args.tv_iters, warm=args.tv_warm, lagged_output=args.tv_lagged, rtol=args.tv_rtol), "l2": lambda: la.L2(sigma=0.05),
           "l1": lambda: la.L1(sigma=tau_reg), "haar": lambda: la.WaveletL1((H, W), sigma=tau_reg)}[args.prior]()
     if args.alg == "ulpda":      # prox_lmc_deconv.py:88-90,455-457: tau0 = 0.95 sigma^2, mu0 = 1, theta = 1, gfirst = False
         pf.niter = args.cg_iters
@@ -268,6 +271,10 @@ def main():
         want = {"H": H, "W": W, "C": C, "prior": args.prior, "data": args.data, "tv_iters": args.tv_iters, "ncvx": args.ncvx}
         if args.blur_k != 5:
             want["blur_k"] = args.blur_k
+        if args.tv_rtol:
+            want["tv_rtol"] = args.tv_rtol
+        if args.ncvx_rtol:
+            want["ncvx_rtol"] = args.ncvx_rtol
         if args.tv_warm:
             want["tv_warm"] = True
         if args.tv_lagged:
@@ -291,7 +298,7 @@ def main():
         per_launch_ms = kern_ms / launches
         its_per_launch = args.steps / launches if timed_launches else 1.0      # 2 where a launch advances every chain by two iterations
         achieved = BYTES_PER_PIXEL_STEP * H * W * C * its_per_launch / (per_launch_ms * 1e-3) / 1e9
-        prior_desc = (f"isotropic TV prox K={args.tv_iters}{' warm-dual' if args.tv_warm else ''}{' lagged output' if args.tv_lagged else ''} (tau_reg={tau_reg})" if args.prior == "tv"
+        prior_desc = (f"isotropic TV prox K={args.tv_iters}{' warm-dual' if args.tv_warm else ''}{' lagged output' if args.tv_lagged else ''}{f' early exit rtol={args.tv_rtol:g}' if args.tv_rtol else ''} (tau_reg={tau_reg})" if args.prior == "tv"
                       else f"{args.prior} prior")
         out = {
             "metric": "lmc_chain_iterations_per_s",
@@ -343,11 +350,23 @@ def main():
             out["roofline"]["actual_bytes_per_launch"] = (BYTES_PER_PIXEL_STEP + 16) * H * W * C
             out["roofline"]["actual_gbs"] = (BYTES_PER_PIXEL_STEP + 16) * H * W * C / (per_launch_ms * 1e-3) / 1e9
             out["config"]["tv_warm"] = True
+        if args.tv_rtol and args.prior == "tv" and args.alg == "myula":
+            try:
+                ps, rr = smp.tv_exit_stats("prior")
+                pc = np.bincount(ps.cpu().numpy(), minlength=args.tv_iters + 1)
+                out["config"]["tv_exit"] = {"passes_histogram_last_iteration": pc.tolist(), "reruns_after_round_1_2_3": rr,
+                                            "chain_iterations": int(C * (args.warmup + args.steps * len(regions)))}
+            except Exception as exc:
+                out["config"]["tv_exit"] = f"pass-by-pass path ({exc})"
+        if args.ncvx_rtol and args.ncvx == "me" and args.alg == "myula":
+            ps, rr = smp.tv_exit_stats("ncvx")
+            pc = np.bincount(ps.cpu().numpy(), minlength=(args.ncvx_iters or args.tv_iters) + 1)
+            out["config"]["ncvx_exit"] = {"passes_histogram_last_iteration": pc.tolist(), "reruns_after_round_1_2_3": rr}
         if args.alg == "mymala":
             out["config"]["acceptance_rate_mean"] = float(smp.acceptance_rate().mean())
             out["config"]["tau_scale"] = args.tau_scale
         if world == 1 and not args.no_cpu_baseline and args.alg == "myula" and args.ncvx == "none" and not args.tv_warm:
-            oprior = {"tv": {"kind": "tv", "sigma": tau_reg, "niter": args.tv_iters - (1 if args.tv_lagged else 0), "t": gamma},
+            oprior = {"tv": {"kind": "tv", "sigma": tau_reg, "niter": args.tv_iters - (1 if args.tv_lagged else 0), "t": gamma, "rtol": args.tv_rtol},
                       "l2": {"kind": "l2", "sigma": 0.05, "t": gamma}, "l1": {"kind": "l1", "sigma": tau_reg, "t": gamma},
                       "haar": {"kind": "haar", "sigma": tau_reg, "t": gamma}}[args.prior]
             if args.data == "blur":

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LMC_ATOMI_ABI_VERSION 2
+#define LMC_ATOMI_ABI_VERSION 3
 
 typedef enum lmc_status {
   LMC_OK = 0,
@@ -111,11 +111,17 @@ typedef struct lmc_problem {
    * LMC_PRIOR_TV_ISO prox and to the inner prox of the ME-TV term. */
   int32_t tv_lagged_output;
   /* pyproximal.TV's per-image early exit on the relative change of the primal objective (its default rtol = 1e-4, which the reference's
-   * call at prox_lmc_deconv.py:122 does not override).  0 (default): off -- every image runs tv_niter dual iterations in one fused launch
-   * (the fast path; statistically equivalent).  > 0: the exact pass-by-pass path for the LMC_PRIOR_TV_ISO prox of MYULA
-   * samplers and lmc_fused_eval: one launch per loop pass for the iterate, one for its objective, images leave individually; the host reads
-   * the number of images still iterating after every pass, so this path SYNCHRONISES the stream (and costs several times the fast path).
-   * Not with tv_warm, MYMALA, or the inner prox of the ME-TV term (which keeps its fixed count). */
+   * call at prox_lmc_deconv.py:122 does not override): at the top of loop pass j >= 1 the iterate x - gamma div(r_j) is returned when
+   * |obj_j - obj_{j-1}| / obj_j < rtol.  0 (default): off -- every image runs tv_niter dual iterations in one fused launch.  > 0: every image
+   * (chain) leaves in the pass the reference's loop leaves it in.  Two implementations, chosen by tv_exit_path:
+   *  - on the device, without synchronisation (ABI 3; the default where the full-width pipeline covers the problem: 128 < W <= 512,
+   *    W % 4 == 0 up to 256 columns and W % 8 == 0 above, tv_niter <= 60): the fused launch runs every chain with a PREDICTED pass count
+   *    (the pass it left in at the previous call), the stages past it hand the dual through, and the primal objectives of all the iterates
+   *    formed are by-products; a one-thread-per-chain kernel replays the exit test on them and the chains whose prediction was wrong
+   *    run again (at most two more rounds settle every chain; the launches of settled chains return at once).
+   *  - pass by pass (ABI 2; everything else): one launch per loop pass for the iterate, one for its objective; the host reads the number
+   *    of images still iterating after every pass, so this path SYNCHRONISES the stream.
+   * Not with tv_warm or MYMALA. */
   float tv_rtol;
   /* Step-kernel variant for launches configured from this problem: 0 = the library default (lmc_set_step_variant, itself "auto"
    * unless changed), 1..7 as listed at lmc_set_step_variant. */
@@ -129,6 +135,26 @@ typedef struct lmc_problem {
    * {1,3} warm-dual reported too".  lmc_sampler_set_state resets the dual to zero.  Needs the full-width pipeline kernel
    * (W > 128, W % 4 == 0 up to 256 columns and W % 8 == 0 above; separable blur / pointwise / no data term), otherwise LMC_E_UNSUPPORTED. */
   int32_t tv_warm;
+  /* ---- ABI 3 ---- */
+  /* The same early exit for the inner prox of the ME-TV term: algs.L2_ncvx_tv builds it as TV(dims, 1., niter, rtol) with the class's own
+   * default rtol = 1e-4 (algs.py:130,169), used by value, gradient and prox of models M3 / M6 / M9 (prox_lmc_deconv.py:111-113).
+   * 0: fixed ncvx_niter updates.  > 0: the device path above over the chained launches (ncvx_niter <= 60, same widths); elsewhere
+   * LMC_E_UNSUPPORTED. */
+  float ncvx_rtol;
+  int32_t tv_exit_path;           /* tv_rtol > 0: 0 = the device path where it covers the problem, 1 = always pass by pass (synchronises) */
+  /* Launch policy of samplers created from this problem (0 = the library decides).  Each field has an environment variable that supplies the
+   * process-wide default when the field is 0; both are read ONCE, when the sampler is created -- never inside lmc_sampler_step.
+   *  iterations_per_launch  (LMC_ITERS_PER_LAUNCH, and the older LMC_ROWS_PAIR / LMC_BLOCK_PAIR / LMC_CHEB_PAIR): 0 = several iterations per
+   *      launch where a kernel covers the configuration and the launch is large enough to pay (two MYULA iterations: separable 5 x 5 box +
+   *      closed-form prior, mask + Haar; two Chebyshev iterations of the implicit step); 1 = always one; 2 = wherever covered (tests).
+   *  moments_overlap  (LMC_MOMENTS_OVERLAP): posterior-moment reductions on a side stream under the next step kernel: 0 = by size, 1 = on, -1 = off.
+   *  moments_bg_workgroups  (LMC_MOMENTS_BG_WGS): workgroups of that background reduction, 0 = by size.
+   *  graph_replay  (LMC_GRAPH): 1 = replay captured hipGraphs of 8 iterations. */
+  int32_t iterations_per_launch;
+  int32_t moments_overlap;
+  int32_t moments_bg_workgroups;
+  int32_t graph_replay;
+  int32_t reserved3[2];
 } lmc_problem;
 
 /* ---- library ------------------------------------------------------------------------- */
@@ -274,6 +300,11 @@ int lmc_sampler_enable_timing(lmc_sampler* s, int32_t on);
 int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_launches);
 /* name of the step kernel variant selected for this configuration (for profiles/) */
 const char* lmc_sampler_kernel_name(const lmc_sampler* s);
+/* Early-exit statistics of the latest TV prox evaluated with tv_rtol > 0 (which = 0) or of the ME-TV inner prox with ncvx_rtol > 0 (which = 1)
+ * on the device path: passes_dev [n_chains] int32 (device, nullable) = the loop pass each chain left in (tv_niter: it ran out of passes);
+ * reruns_host[3] (host, nullable) = chains whose run had to be repeated after round 1 / 2 / 3 of the latest call, summed over all calls since
+ * creation (round 3's count stays 0 by construction).  Synchronises `stream`.  LMC_E_STATE when the sampler does not use the device path. */
+int lmc_sampler_tv_exit_stats(lmc_sampler* s, int32_t which, int32_t* passes_dev, uint64_t* reruns_host, void* stream);
 
 /* ---- multi-GPU: the one collective of the path ----------------------------------------------
  * Chains are sharded over GPUs by global chain id (chain_offset), one process per GPU, no data-path collective.  The only

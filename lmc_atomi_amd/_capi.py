@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblmc_atomi.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enums (include/lmc_atomi.h)
 DATA_NONE, DATA_IDENTITY, DATA_BLUR, DATA_MASK = 0, 1, 2, 3
@@ -58,6 +58,14 @@ class lmc_problem(C.Structure):
         ("step_variant", C.c_int32),
         ("implicit_tol", C.c_float),
         ("tv_warm", C.c_int32),
+        # ABI 3
+        ("ncvx_rtol", C.c_float),
+        ("tv_exit_path", C.c_int32),
+        ("iterations_per_launch", C.c_int32),
+        ("moments_overlap", C.c_int32),
+        ("moments_bg_workgroups", C.c_int32),
+        ("graph_replay", C.c_int32),
+        ("reserved3", C.c_int32 * 2),
     ]
 
 
@@ -128,6 +136,7 @@ _SIGNATURES = {
     "lmc_sampler_enable_timing": (C.c_int, [_P, C.c_int32]),
     "lmc_sampler_last_step_timing": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "lmc_sampler_kernel_name": (C.c_char_p, [_P]),
+    "lmc_sampler_tv_exit_stats": (C.c_int, [_P, C.c_int32, _P, C.POINTER(C.c_uint64), _P]),
     "lmc_set_step_variant": (C.c_int, [C.c_int32]),
     "lmc_ulpda_create": (C.c_int, [C.POINTER(lmc_ulpda_config), C.POINTER(_P)]),
     "lmc_sampler_set_dual": (C.c_int, [_P, _P, _P]),

@@ -50,7 +50,7 @@ class MYULASampler:
     """
 
     def __init__(self, proxf, proxg, dims, n_chains=1, tau=None, gamma=0.1, epsg=1.0, seed=0,
-                 chain_offset=0, noise="philox", moments=False, burn_in=0, thin=1, device=None, variant=None, tv_warm=None):
+                 chain_offset=0, noise="philox", moments=False, burn_in=0, thin=1, device=None, variant=None, tv_warm=None, policy=None):
         """``variant``: step-kernel variant of THIS sampler ('auto' | 'tile' | 'split' | 'point' | 'block' | 'rows' | 'pipe'; None = the
         library default, :func:`set_step_variant`).  ``tv_warm``: carry the TV dual between iterations (see :class:`TV`; None = as
         ``proxg.warm`` says).  Every call on the sampler runs on ``device`` whatever the current device is."""
@@ -63,6 +63,9 @@ class MYULASampler:
         opts = {"step_variant": variant or 0}
         if tv_warm is not None:
             opts["tv_warm"] = bool(tv_warm)
+        # launch policy of this sampler (lmc_problem, ABI 3): dict with any of iterations_per_launch (0 auto / 1 / 2), moments_overlap (0 auto /
+        # 1 / -1), moments_bg_workgroups, graph_replay, tv_exit_path (1 = the pass-by-pass early exit)
+        opts.update(policy or {})
         self._problem = _Problem(self.dims, _data_descriptor(proxf), _prior_descriptor(proxg), self.device, options=opts)
         cfg = _capi.lmc_myula_config()
         cfg.struct_size = C.sizeof(_capi.lmc_myula_config)
@@ -152,6 +155,15 @@ class MYULASampler:
     @property
     def kernel_name(self):
         return _dev.lib().lmc_sampler_kernel_name(self._h).decode()
+
+    def tv_exit_stats(self, which="prior"):
+        """Early-exit statistics of the device path (``TV(rtol > 0)`` / ``L2_ncvx_tv(rtol > 0)``): ``(passes, reruns)`` -- the loop pass each
+        chain's latest prox left in (int32 tensor, ``niter`` = it ran out of passes) and the number of chain runs that had to be repeated
+        after rounds 1 / 2 / 3 since the sampler was created (``which``: 'prior' = the TV prior's prox, 'ncvx' = the ME-TV inner prox)."""
+        passes = torch.empty(self.n_chains, dtype=torch.int32, device=self.device)
+        rr = (C.c_uint64 * 3)()
+        _capi.check(_dev.lib().lmc_sampler_tv_exit_stats(self._h, {"prior": 0, "ncvx": 1}[which], _dev.ptr(passes), rr, _dev.stream_ptr(self.device)))
+        return passes, [int(v) for v in rr]
 
     # -- diagnostics ---------------------------------------------------------------------
     def energies(self):

@@ -73,9 +73,43 @@ struct Problem {
   float ncvx_lambda = 0.f, ncvx_gamma = 1.f;
   int ncvx_niter = 0;
   int tv_warm = 0;
-  float tv_rtol = 0.f;      // > 0: pyproximal.TV's per-image early exit (exact pass-by-pass path, tv_prox_rtol)
+  float tv_rtol = 0.f;      // > 0: pyproximal.TV's per-image early exit (device path tv_prox_rt, or the pass-by-pass path tv_prox_rtol)
+  float ncvx_rtol = 0.f;    // > 0: the same for the inner prox of the ME-TV term (device path only)
+  int tv_exit_path = 0;     // 1: always pass by pass
+  int iters_per_launch = 0, moments_overlap = 0, moments_bg_wgs = 0, graph_replay = 0;   // launch policy (0 = library decides; fixed at sampler creation)
+  int cheb_pair = 1;        // two Chebyshev iterations per launch: 0 never, 1 where they pay, 2 wherever covered
   int variant = 0;          // 0: the library default (g_variant)
   float implicit_tol = 0.f; // 0: the library default (g_cg_tol); < 0: disabled
+};
+
+// Buffers of the device-side early exit of a TV prox (tv_prox_rt): per chain the pass count of the current round (kc; -1 = settled), the pass it left
+// in at the previous call (pred: the prediction of the next one), the primal objectives of the iterates [n][stride], and three counters of re-runs.
+struct RtState {
+  int* kc = nullptr;
+  int* pred = nullptr;
+  double* obj = nullptr;
+  unsigned long long* reruns = nullptr;
+  int stride = 0;
+  size_t n = 0;
+  hipError_t need(size_t n_img, int niter) {
+    if (n_img <= n && niter + 1 <= stride) return hipSuccess;
+    release();
+    hipError_t e = hipMalloc(&kc, sizeof(int) * n_img);
+    if (e == hipSuccess) e = hipMalloc(&pred, sizeof(int) * n_img);
+    if (e == hipSuccess) e = hipMalloc(&obj, sizeof(double) * n_img * (size_t)(niter + 1));
+    if (e == hipSuccess) e = hipMalloc(&reruns, sizeof(unsigned long long) * 3);
+    if (e == hipSuccess) e = hipMemset(pred, 0, sizeof(int) * n_img);           // 0 = no prediction yet: the first call runs every pass
+    if (e == hipSuccess) e = hipMemset(reruns, 0, sizeof(unsigned long long) * 3);
+    if (e == hipSuccess) { n = n_img; stride = niter + 1; }
+    return e;
+  }
+  void release() {
+    if (kc) (void)hipFree(kc);
+    if (pred) (void)hipFree(pred);
+    if (obj) (void)hipFree(obj);
+    if (reruns) (void)hipFree(reruns);
+    kc = pred = nullptr; obj = nullptr; reruns = nullptr; n = 0; stride = 0;
+  }
 };
 
 // Device scratch for the stateless entry points (grown on demand, kept for the life of the process; calls are
@@ -95,6 +129,7 @@ struct Scratch {
     return e;
   }
   double* dbl = nullptr;                  // 2*n doubles
+  RtState rt_tv, rt_me;                   // device-side early exit of the TV prior's prox / of the ME-TV inner prox
   size_t n_state = 0, n_extra = 0, n_dbl = 0, n_prox = 0;
   hipError_t need_prox(size_t n) {
     if (n <= n_prox) return hipSuccess;
@@ -214,6 +249,23 @@ int load_problem(const lmc_problem* p, Problem& q) {
     // the sign as "component-wise weights 1 / max(|d|, gamma)" instead of the pixel norm; every MC-TV code path serves both
     if (p->ncvx_kind == LMC_NCVX_MC_TV_ANISO) { q.ncvx_kind = LMC_NCVX_MC_TV; q.ncvx_gamma = -p->ncvx_gamma; }
     q.ncvx_niter = p->ncvx_niter - ((p->ncvx_kind == LMC_NCVX_ME_TV && p->tv_lagged_output) ? 1 : 0);
+    if (p->ncvx_kind == LMC_NCVX_ME_TV) {
+      if (!(p->ncvx_rtol >= 0.f) || p->ncvx_rtol >= 1.f) return fail(LMC_E_INVALID, "ncvx_rtol must be in [0, 1)");
+      q.ncvx_rtol = p->ncvx_rtol;
+    }
+  }
+  if (p->tv_exit_path != 0 && p->tv_exit_path != 1) return fail(LMC_E_INVALID, "tv_exit_path must be 0 (device path where covered) or 1 (pass by pass)");
+  q.tv_exit_path = p->tv_exit_path;
+  if (p->iterations_per_launch < 0 || p->iterations_per_launch > 2) return fail(LMC_E_INVALID, "iterations_per_launch must be 0 (auto), 1 or 2");
+  if (p->moments_overlap < -1 || p->moments_overlap > 1) return fail(LMC_E_INVALID, "moments_overlap must be 0 (auto), 1 (on) or -1 (off)");
+  if (p->moments_bg_workgroups < 0 || p->graph_replay < 0 || p->graph_replay > 1) return fail(LMC_E_INVALID, "bad moments_bg_workgroups / graph_replay");
+  q.iters_per_launch = p->iterations_per_launch; q.moments_overlap = p->moments_overlap;
+  q.moments_bg_wgs = p->moments_bg_workgroups; q.graph_replay = p->graph_replay;
+  {
+    const char* e = getenv("LMC_CHEB_PAIR");
+    const char* e2 = getenv("LMC_ITERS_PER_LAUNCH");
+    const int ipl = q.iters_per_launch ? q.iters_per_launch : (e2 ? atoi(e2) : 0);
+    q.cheb_pair = ipl == 1 ? 0 : (ipl == 2 ? 2 : (e ? atoi(e) : 1));
   }
   if (p->step_variant < 0 || p->step_variant > 7 || p->step_variant == 2)
     return fail(LMC_E_INVALID, "step_variant %d: 0 (library default), 1 tile, 3 split, 4 point, 5 block, 6 rows, 7 pipe", p->step_variant);
@@ -395,10 +447,9 @@ static hipError_t chebyshev_solve(const Problem& q, float ts, float* u, const fl
   static const int64_t env_chunk = [] { const char* e = getenv("LMC_CHEB_CHUNK"); return e ? (int64_t)atoll(e) : 0; }();
   const int64_t chunk = env_chunk > 0 && env_chunk < C ? env_chunk : C;
   const size_t img = (size_t)q.H * q.W;
-  // LMC_CHEB_PAIR: 0 = single-iteration launches only, 2 = pairs wherever the kernel covers the problem (tests), default = where they pay;
-  // read per call so that a test can switch it
-  const char* pair_env = getenv("LMC_CHEB_PAIR");
-  const int pair_mode = pair_env ? atoi(pair_env) : 1;
+  // lmc_problem.iterations_per_launch / LMC_CHEB_PAIR (resolved when the problem is loaded: sampler creation, or the stateless call): 0 = single-iteration
+  // launches only, 2 = pairs wherever the kernel covers the problem (tests), default = where they pay
+  const int pair_mode = q.cheb_pair;
   const bool pair_on = pair_mode == 2 || (pair_mode == 1 && lmc::cheb_pair_pays(C, q.H));
   if (pb && result && pair_on && chunk == C && K >= 4 && 2 * ((K + 1) / 2) <= niter_cap && delta > 1e-12 * theta &&
       lmc::cheb_pair_supported(q.H, q.W, q.taps)) {      // (pairs never run more iterations than the caller's cap)
@@ -553,11 +604,35 @@ int cg_solve_fused(const Problem& q, float ts, float* u, const float* rhs, float
 }
 
 bool needs_tv_state(const Problem& q) {
-  return (q.prior_kind == LMC_PRIOR_TV_ISO && q.tv_niter > 12) || (q.ncvx_kind == LMC_NCVX_ME_TV && q.ncvx_niter > 12);
+  return (q.prior_kind == LMC_PRIOR_TV_ISO && (q.tv_niter > 12 || (q.tv_rtol > 0.f && q.tv_niter > 10))) ||
+         (q.ncvx_kind == LMC_NCVX_ME_TV && (q.ncvx_niter > 12 || (q.ncvx_rtol > 0.f && q.ncvx_niter > 10)));
 }
 
+// The TV prox inside A (a complete StepArgs: prox only, or the whole fused update when A.tv.niter <= 10) with upstream's per-image early exit,
+// decided on the device: every chain runs with the pass count it left in last time (rt.pred), the launch leaves the primal objectives of
+// the iterates behind, tv_rt_decide replays upstream's test on them, and the chains whose prediction was wrong run again -- with the exact
+// count when the objectives already show it, else with all passes (whose objectives show it) and then once more.  Three rounds settle
+// every chain; the workgroups of settled chains return at once, so rounds two and three cost a few microseconds when the predictions hold.
+// No host synchronisation.  (lmc_ops.hip: tv_rt_begin / tv_rt_decide; lmc_step_pipe_rt.hip.)
+int tv_prox_rt(lmc::StepArgs A, RtState& rt, float rtol, float* st0, float* st1, hipStream_t st) {
+  const int niter = A.tv.niter;
+  if (!rt.kc || rt.n < (size_t)A.C || rt.stride < niter + 1) return fail(LMC_E_STATE, "early-exit buffers are missing");
+  A.rt_kc = rt.kc; A.rt_obj = rt.obj; A.rt_stride = rt.stride;
+  HIP_TRY(lmc::launch_tv_rt_begin(A.C, rt.pred, rt.kc, rt.obj, rt.stride, niter, st));
+  for (int round = 0; round < 3; ++round) {
+    hipError_t e = lmc::launch_step_pipe_rt(A, st, st0, st1);
+    if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "the device-side early exit of the TV prox does not cover this configuration");
+    HIP_TRY(e);
+    HIP_TRY(lmc::launch_tv_rt_decide(A.C, rt.kc, rt.pred, rt.obj, rt.stride, niter, (double)rtol, rt.reruns + round, st));
+  }
+  return LMC_OK;
+}
+
+int tv_prox_rtol(const Problem& q, float pt, const float* x, float* sol, float* tmp, double* obj, int* flag, int64_t n, float* st0, float* st1,
+                 hipStream_t st);
+
 // extra <- prox_{gamma TV}(x) with ncvx_niter dual iterations (the inner prox of the ME-TV term, algs.py:169,282)
-int me_tv_prox(const Problem& q, const float* x, float* extra, int64_t n_img, float* state0, float* state1, hipStream_t st) {
+int me_tv_prox(const Problem& q, const float* x, float* extra, int64_t n_img, float* state0, float* state1, hipStream_t st, RtState* rt = nullptr) {
   lmc::StepArgs A;
   std::memset(&A, 0, sizeof A);
   A.H = q.H; A.W = q.W; A.C = (int)n_img;
@@ -574,6 +649,19 @@ int me_tv_prox(const Problem& q, const float* x, float* extra, int64_t n_img, fl
   if (q.ncvx_niter == 0) {     // lagged output of a 1-iteration prox: x itself
     HIP_TRY(hipMemcpyAsync(extra, x, sizeof(float) * (size_t)n_img * q.H * q.W, hipMemcpyDeviceToDevice, st));
     return LMC_OK;
+  }
+  if (q.ncvx_rtol > 0.f) {     // the class's own rtol (algs.py:130,169): per-chain early exit
+    if (rt && q.tv_exit_path == 0 && lmc::pipe_rt_supported(A)) return tv_prox_rt(A, *rt, q.ncvx_rtol, state0, state1, st);     // on the device
+    // elsewhere (narrow / wide / unaligned images): pass by pass, as the TV prior's prox (synchronises the stream)
+    Problem qt;
+    qt.H = q.H; qt.W = q.W;
+    qt.prior_kind = LMC_PRIOR_TV_ISO; qt.prior_sigma = 1.f; qt.tv_niter = q.ncvx_niter; qt.tv_step = 0.125f; qt.tv_rtol = q.ncvx_rtol;
+    default_betas(qt.betas, q.ncvx_niter);
+    qt.variant = q.variant;
+    Scratch& sc = g_scratch;
+    HIP_TRY(sc.need_rtmp((size_t)n_img * q.H * q.W));
+    HIP_TRY(sc.need_dbl(3 * (size_t)n_img + 2));
+    return tv_prox_rtol(qt, q.ncvx_gamma, x, extra, sc.rtmp, sc.dbl, reinterpret_cast<int*>(sc.dbl + 2 * n_img), n_img, state0, state1, st);
   }
   hipError_t e = launch_step(A, variant_of(q), st, nullptr, state0, state1);
   if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "no kernel covers the inner TV prox of the ME-TV term");
@@ -631,6 +719,43 @@ int tv_prox_rtol(const Problem& q, float pt, const float* x, float* sol, float* 
   }
   return LMC_OK;
 }
+
+// The TV PRIOR's prox with the early exit on the device.  A: the complete fused update (x_in, x_out, data term, noise ...).  Returns 1 when the
+// update has been computed (up to 10 passes: the exit lives inside the fused step launch), 0 when the prox alone went to `proxbuf` and A now
+// consumes it as a ready-made prox (more than 10 passes, or a data term the pipeline does not cover: the caller launches the step), 2 when the
+// device path does not cover the problem (the caller takes the pass-by-pass path), or a negative status.
+int tv_prior_rt(const Problem& q, float pt, lmc::StepArgs& A, RtState& rt, float* proxbuf, float* st0, float* st1, hipStream_t st) {
+  if (A.tv.niter <= 10 && lmc::pipe_rt_supported(A)) {
+    const int rc = tv_prox_rt(A, rt, q.tv_rtol, st0, st1, st);
+    return rc ? rc : 1;
+  }
+  Problem qp = q;
+  qp.ncvx_kind = LMC_NCVX_NONE;
+  lmc::StepArgs P;
+  int rc = make_step_args(qp, 0.f, 0.f, 1.f, pt, 0.f, P);
+  if (rc) return rc;
+  P.C = A.C; P.x_in = A.x_in; P.x_out = proxbuf;
+  sanitize_pointers(P);
+  if (!proxbuf || !lmc::pipe_rt_supported(P)) return 2;
+  rc = tv_prox_rt(P, rt, q.tv_rtol, st0, st1, st);
+  if (rc) return rc;
+  A.prior_kind = LMC_PRIOR_NONE;
+  A.prox_ext = proxbuf;
+  return 0;
+}
+// which of the two the sampler / call will take: 1 fused, 0 prox alone, 2 not covered
+int tv_prior_rt_mode(const Problem& q, const lmc::StepArgs& A_probe, float pt) {
+  if (q.tv_exit_path != 0) return 2;
+  if (A_probe.tv.niter <= 10 && lmc::pipe_rt_supported(A_probe)) return 1;
+  Problem qp = q;
+  qp.ncvx_kind = LMC_NCVX_NONE;
+  lmc::StepArgs P;
+  if (make_step_args(qp, 0.f, 0.f, 1.f, pt, 0.f, P)) return 2;
+  P.C = A_probe.C;
+  return lmc::pipe_rt_supported(P) ? 0 : 2;
+}
+
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 }  // namespace
 
 struct lmc_sampler {
@@ -652,7 +777,16 @@ struct lmc_sampler {
   int wcur = 0;
   float* extra = nullptr;                   // ME-TV inner prox
   float* pxbuf = nullptr;                   // Haar-l1 prox / early-exit TV prox of the current state
-  float* rtmp = nullptr; double* robj = nullptr; int* rflag = nullptr;   // early-exit TV prox (tv_rtol > 0): pass iterate, objectives, flags
+  float* rtmp = nullptr; double* robj = nullptr; int* rflag = nullptr;   // early-exit TV prox (tv_rtol > 0), pass-by-pass path: pass iterate, objectives, flags
+  RtState rt_tv, rt_me;                     // early-exit TV prox on the device (tv_prox_rt): of the TV prior / of the ME-TV inner prox
+  // launch policy, fixed at creation (lmc_problem fields; their environment variables supply the defaults): see lmc_atomi.h
+  int pol_pair = 1;          // 0 never, 1 where it pays, 2 wherever covered: two MYULA iterations per launch (rows kernel)
+  int pol_blockpair = 1;     // 0 / 1: two or four iterations per launch on the block kernel
+  int pol_overlap = 0;       // 0 by size, 1 on, -1 off
+  int pol_bg_wgs = -1;       // workgroups of the background reduction, -1 by size
+  int pol_graph = 0;
+  int pol_side_lowprio = 1;
+  bool pol_ulpda_dual_rhs = false;   // ULPDA, opt-in experiment (LMC_ULPDA_DUAL_RHS=1 at creation): dual update fused with the next right-hand side
   Problem prob;
   int C = 0;
   int64_t chain_offset = 0;
@@ -788,13 +922,23 @@ int lmc_fused_eval(const lmc_problem* prob, const float* x_dev, float* out_dev, 
   if (needs_tv_state(q)) HIP_TRY(g_scratch.need_state(4 * npx));
   if (t != 0.f && q.ncvx_kind == LMC_NCVX_ME_TV) {
     HIP_TRY(g_scratch.need_extra(npx));
-    rc = me_tv_prox(q, x_dev, g_scratch.extra, n_img, g_scratch.state[0], g_scratch.state[1], S(stream));
+    if (q.ncvx_rtol > 0.f) HIP_TRY(g_scratch.rt_me.need((size_t)n_img, q.ncvx_niter));
+    rc = me_tv_prox(q, x_dev, g_scratch.extra, n_img, g_scratch.state[0], g_scratch.state[1], S(stream), &g_scratch.rt_me);
     if (rc) return rc;
     A.extra = g_scratch.extra;
     A.extra_coef = -q.ncvx_lambda / q.ncvx_gamma;
   }
   if (A.prior_kind == LMC_PRIOR_HAAR_L1) HIP_TRY(g_scratch.need_prox(npx));
-  if (A.prior_kind == LMC_PRIOR_TV_ISO && q.tv_rtol > 0.f) {     // the early-exit prox first, then the fused update with it as a ready-made prox
+  if (A.prior_kind == LMC_PRIOR_TV_ISO && q.tv_rtol > 0.f && tv_prior_rt_mode(q, A, pt) != 2) {     // the early exit decided on the device
+    Scratch& sc = g_scratch;
+    HIP_TRY(sc.need_prox(npx));
+    HIP_TRY(sc.rt_tv.need((size_t)n_img, q.tv_niter));
+    if (needs_tv_state(q)) HIP_TRY(sc.need_state(4 * npx));
+    rc = tv_prior_rt(q, pt, A, sc.rt_tv, sc.prox, sc.state[0], sc.state[1], S(stream));
+    if (rc < 0) return rc;
+    if (rc == 1) return LMC_OK;
+    if (rc == 2) return fail(LMC_E_UNSUPPORTED, "early exit of the TV prox: no path covers this configuration");
+  } else if (A.prior_kind == LMC_PRIOR_TV_ISO && q.tv_rtol > 0.f) {     // the early-exit prox first, then the fused update with it as a ready-made prox
     Scratch& sc = g_scratch;
     HIP_TRY(sc.need_prox(npx));
     HIP_TRY(sc.need_rtmp(npx));
@@ -821,8 +965,8 @@ static lmc::EnergyArgs energy_args(const Problem& q) {
 
 // f_out -= lambda * ( TV(prox) + ||x - prox||^2 / (2 gamma) ),  prox = prox_{gamma TV}(x)    (algs.py:178-190, ME-TV)
 static int me_tv_energy(const Problem& q, const float* x, int64_t n_img, double* f_out, float* extra, float* st0, float* st1,
-                        double* dbl /* 2*n_img */, hipStream_t st) {
-  int rc = me_tv_prox(q, x, extra, n_img, st0, st1, st);
+                        double* dbl /* 2*n_img */, hipStream_t st, RtState* rt) {
+  int rc = me_tv_prox(q, x, extra, n_img, st0, st1, st, rt);
   if (rc) return rc;
   lmc::EnergyArgs E;
   std::memset(&E, 0, sizeof E);
@@ -845,8 +989,9 @@ int lmc_energies(const lmc_problem* prob, const float* x_dev, int64_t n_img, dou
     const size_t npx = (size_t)n_img * q.H * q.W;
     HIP_TRY(g_scratch.need_state(4 * npx));
     HIP_TRY(g_scratch.need_extra(npx));
-    HIP_TRY(g_scratch.need_dbl(2 * (size_t)n_img));
-    rc = me_tv_energy(q, x_dev, n_img, f_out_dev, g_scratch.extra, g_scratch.state[0], g_scratch.state[1], g_scratch.dbl, S(stream));
+    HIP_TRY(g_scratch.need_dbl(3 * (size_t)n_img + 2));     // (the pass-by-pass fallback of the inner prox shares the buffer: sized for it up front)
+    if (q.ncvx_rtol > 0.f) HIP_TRY(g_scratch.rt_me.need((size_t)n_img, q.ncvx_niter));
+    rc = me_tv_energy(q, x_dev, n_img, f_out_dev, g_scratch.extra, g_scratch.state[0], g_scratch.state[1], g_scratch.dbl, S(stream), &g_scratch.rt_me);
     if (rc) return rc;
   }
   return LMC_OK;
@@ -885,7 +1030,8 @@ int lmc_l2_prox(const lmc_problem* prob, const float* x_dev, float* out_dev, int
   } else if (q.ncvx_kind == LMC_NCVX_ME_TV) {
     HIP_TRY(g_scratch.need_extra(n));
     if (needs_tv_state(q)) HIP_TRY(g_scratch.need_state(4 * n));
-    rc = me_tv_prox(q, x_dev, g_scratch.extra, n_img, g_scratch.state[0], g_scratch.state[1], st);
+    if (q.ncvx_rtol > 0.f) HIP_TRY(g_scratch.rt_me.need((size_t)n_img, q.ncvx_niter));
+    rc = me_tv_prox(q, x_dev, g_scratch.extra, n_img, g_scratch.state[0], g_scratch.state[1], st, &g_scratch.rt_me);
     if (rc) return rc;
     HIP_TRY(lmc::ulpda_me_rhs(x_dev, g_scratch.extra, tmp, rhs, n_img, q.H, q.W, tau * q.ncvx_lambda / q.ncvx_gamma, ts, st));
   } else {
@@ -980,10 +1126,25 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
   if (e == hipSuccess && s->prob.prior_kind == LMC_PRIOR_HAAR_L1) e = hipMalloc(&s->pxbuf, nbytes);
   if (e == hipSuccess && s->prob.tv_rtol > 0.f && s->base.prior_kind == LMC_PRIOR_TV_ISO) {
     if (s->prob.tv_warm) { lmc_sampler_destroy(s); return fail(LMC_E_UNSUPPORTED, "tv_rtol > 0 and tv_warm exclude each other"); }
-    e = hipMalloc(&s->pxbuf, nbytes);
-    if (e == hipSuccess) e = hipMalloc(&s->rtmp, nbytes);
-    if (e == hipSuccess) e = hipMalloc(&s->robj, sizeof(double) * 2 * (size_t)s->C);
-    if (e == hipSuccess) e = hipMalloc(&s->rflag, sizeof(int) * ((size_t)s->C + 1));
+    const int mode = tv_prior_rt_mode(s->prob, s->base, s->epsg * s->gamma);     // 1: inside the fused launch, 0: prox alone, 2: pass by pass
+    if (mode != 2) e = s->rt_tv.need((size_t)s->C, s->prob.tv_niter);
+    if (e == hipSuccess && mode != 1 && !s->pxbuf) e = hipMalloc(&s->pxbuf, nbytes);
+    if (mode == 2) {
+      if (e == hipSuccess) e = hipMalloc(&s->rtmp, nbytes);
+      if (e == hipSuccess) e = hipMalloc(&s->robj, sizeof(double) * 2 * (size_t)s->C);
+      if (e == hipSuccess) e = hipMalloc(&s->rflag, sizeof(int) * ((size_t)s->C + 1));
+    }
+  }
+  if (e == hipSuccess && s->prob.ncvx_kind == LMC_NCVX_ME_TV && s->prob.ncvx_rtol > 0.f) e = s->rt_me.need((size_t)s->C, s->prob.ncvx_niter);
+  {   // launch policy: the lmc_problem fields, their environment variables where a field is 0 -- read here, once, never inside lmc_sampler_step
+    const Problem& q = s->prob;
+    const int ipl = q.iters_per_launch ? q.iters_per_launch : env_int("LMC_ITERS_PER_LAUNCH", 0);
+    s->pol_pair = ipl == 1 ? 0 : (ipl == 2 ? 2 : env_int("LMC_ROWS_PAIR", 1));
+    s->pol_blockpair = ipl == 1 ? 0 : (ipl == 2 ? 1 : (env_int("LMC_BLOCK_PAIR", 1) != 0));
+    s->pol_overlap = q.moments_overlap ? q.moments_overlap : (getenv("LMC_MOMENTS_OVERLAP") ? (env_int("LMC_MOMENTS_OVERLAP", 0) ? 1 : -1) : 0);
+    s->pol_bg_wgs = q.moments_bg_wgs > 0 ? q.moments_bg_wgs : env_int("LMC_MOMENTS_BG_WGS", -1);
+    s->pol_graph = q.graph_replay ? 1 : (env_int("LMC_GRAPH", 0) == 1);
+    s->pol_side_lowprio = env_int("LMC_MOMENTS_SIDE_PRIO", 1) != 0;
   }
   if (e == hipSuccess && s->prob.tv_warm) {
     lmc::StepArgs probe = s->base;
@@ -1023,6 +1184,8 @@ void lmc_sampler_destroy(lmc_sampler* s) {
     if (b) (void)hipFree(b);
   if (s->robj) (void)hipFree(s->robj);
   if (s->rflag) (void)hipFree(s->rflag);
+  s->rt_tv.release();
+  s->rt_me.release();
   if (s->mala_d) (void)hipFree(s->mala_d);
   if (s->flag) (void)hipFree(s->flag);
   if (s->nacc) (void)hipFree(s->nacc);
@@ -1072,8 +1235,8 @@ static int sampler_energies_at(lmc_sampler* s, const float* x, double* f_out_dev
   if (s->prob.prior_kind == LMC_PRIOR_HAAR_L1 && g_out_dev)
     HIP_TRY(lmc::launch_haar_value(x, s->C, s->prob.H, s->prob.W, s->prob.prior_sigma, g_out_dev, st));
   if (s->prob.ncvx_kind == LMC_NCVX_ME_TV && f_out_dev) {
-    HIP_TRY(g_scratch.need_dbl(2 * (size_t)s->C));
-    int rc = me_tv_energy(s->prob, x, s->C, f_out_dev, s->extra, s->tvstate[0], s->tvstate[1], g_scratch.dbl, st);
+    HIP_TRY(g_scratch.need_dbl(3 * (size_t)s->C + 2));
+    int rc = me_tv_energy(s->prob, x, s->C, f_out_dev, s->extra, s->tvstate[0], s->tvstate[1], g_scratch.dbl, st, &s->rt_me);
     if (rc) return rc;
   }
   return LMC_OK;
@@ -1101,7 +1264,7 @@ static int sampler_update(lmc_sampler* s, const float* x_in, float* x_out, bool 
   if (!with_noise) { A.s = 0.f; A.noise_mode = LMC_NOISE_NONE; A.noise = nullptr; }
   sanitize_pointers(A);
   if (s->prob.ncvx_kind == LMC_NCVX_ME_TV) {   // inner prox of the Moreau-envelope term, then the fused step
-    int rc = me_tv_prox(s->prob, A.x_in, s->extra, s->C, s->tvstate[0], s->tvstate[1], st);
+    int rc = me_tv_prox(s->prob, A.x_in, s->extra, s->C, s->tvstate[0], s->tvstate[1], st, &s->rt_me);
     if (rc) return rc;
     A.extra = s->extra;
     A.extra_coef = -s->prob.ncvx_lambda / s->prob.ncvx_gamma;
@@ -1117,12 +1280,11 @@ static int sampler_update(lmc_sampler* s, const float* x_in, float* x_out, bool 
 constexpr int kGraphIters = 8;     // iterations per graph launch (even: the ping-pong buffers are back in place)
 
 static bool graph_wanted(const lmc_sampler* s) {
-  const char* env = getenv("LMC_GRAPH");          // 0 off, 1 on, unset: by size (read at every call: tests flip it)
-  // Opt-in (LMC_GRAPH=1).  Measured on ROCm 7.2 / MI355X at BASELINE config 2 (256 x 256 x 128, rows kernel 25 us + reduction 15.6 us): plain
+  // Opt-in (lmc_problem.graph_replay / LMC_GRAPH=1, fixed when the sampler is created).  Measured on ROCm 7.2 / MI355X at BASELINE config 2 (256 x 256 x 128, rows kernel 25 us + reduction 15.6 us): plain
   // launches 40.2 us per iteration -- the queue is never empty, there are no launch gaps to recover -- graph replay 42.0 us (the side branch
   // does not run under the next step kernel); what does help is the reduction on a second HIP stream (LMC_MOMENTS_OVERLAP, default for small
   // configurations): 37.1 us.  Kept because the replay is exact (tests/test_gpu_graph.py) and may pay on another runtime.
-  return env && atoi(env) == 1;
+  return s->pol_graph != 0;
 }
 
 // Captures kGraphIters iterations starting from buffer s->cur into an executable graph.
@@ -1222,28 +1384,25 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
   // reduction under the step kernel costs that kernel 6 % (1.76 -> 1.89 ms per launch) and saves its own 0.22 ms -- 1.976 -> 1.90-1.92 ms per
   // iteration with 256 workgroups (16: 3.19, 64: 2.07, 128: 1.92, 256: 1.90, 512: 1.94, 1024: 1.98 ms; too few and the reduction outlasts the
   // step kernel) -- a 3.5 % gain that is left opt-in so that the step kernel's launch time in bench.py / profiles/ is that of the kernel alone.
-  const char* ov_env = getenv("LMC_MOMENTS_OVERLAP");
-  const bool want_overlap = ov_env ? atoi(ov_env) != 0 : (long long)s->C * s->prob.H * s->prob.W <= (1LL << 25);
-  static const int bg_env = [] { const char* e = getenv("LMC_MOMENTS_BG_WGS"); return e ? atoi(e) : -1; }();   // 0: the full-speed kernel
-  const int bg_wgs = bg_env >= 0 ? bg_env : ((long long)s->C * s->prob.H * s->prob.W <= (1LL << 25) ? 128 : 256);
+  // (policy: lmc_problem.moments_overlap / moments_bg_workgroups, LMC_MOMENTS_OVERLAP / LMC_MOMENTS_BG_WGS as defaults; fixed at creation)
+  const bool want_overlap = s->pol_overlap ? s->pol_overlap > 0 : (long long)s->C * s->prob.H * s->prob.W <= (1LL << 25);
+  const int bg_wgs = s->pol_bg_wgs >= 0 ? s->pol_bg_wgs : ((long long)s->C * s->prob.H * s->prob.W <= (1LL << 25) ? 128 : 256);   // 0: the full-speed kernel
   bool overlap = want_overlap && s->moments && n_iters > 1;
   if (overlap && !s->side) {
     int prio_least = 0, prio_greatest = 0;     // lowest priority: the step kernel's workgroups go first
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    static const bool low_prio = [] { const char* e = getenv("LMC_MOMENTS_SIDE_PRIO"); return !e || atoi(e) != 0; }();
+    const bool low_prio = s->pol_side_lowprio != 0;
     if (low_prio) HIP_TRY(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_least));
     else HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_step, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&s->ev_mom[i], hipEventDisableTiming));
   }
   // graph replay: whole blocks of kGraphIters iterations whose every iteration is kept by the moment accumulators (or none is)
-  const bool graph_ok = !s->timing && (!overlap || (getenv("LMC_GRAPH") && atoi(getenv("LMC_GRAPH")) == 1)) && !noise_dev && s->noise_mode != LMC_NOISE_INJECTED && s->prob.ncvx_kind != LMC_NCVX_ME_TV &&
-                        !s->tvwarm[0] && !s->rtmp && (!s->moments || s->thin == 1) && graph_wanted(s);
+  const bool graph_ok = !s->timing && (!overlap || s->pol_graph) && !noise_dev && s->noise_mode != LMC_NOISE_INJECTED && s->prob.ncvx_kind != LMC_NCVX_ME_TV &&
+                        !s->tvwarm[0] && !s->rtmp && !s->rt_tv.kc && (!s->moments || s->thin == 1) && graph_wanted(s);
   bool graph_enabled = false;
-  const char* pair_env = getenv("LMC_ROWS_PAIR");
-  const int pair_mode = pair_env ? atoi(pair_env) : 1;
-  const char* bp_env = getenv("LMC_BLOCK_PAIR");
-  const bool blockpair_on = !bp_env || atoi(bp_env) != 0;
+  const int pair_mode = s->pol_pair;
+  const bool blockpair_on = s->pol_blockpair != 0;
   for (int k = 0; k < n_iters; ++k) {
     if (graph_ok && s->plain_done && n_iters - k >= kGraphIters && (!s->moments || s->iteration >= s->burn_in) &&
         (s->kernel_name == "myula_step_rows_kernel" || s->kernel_name == "myula_step_block_kernel" || s->kernel_name == "myula_step_pipe_kernel")) {
@@ -1265,7 +1424,7 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     }
     // Two MYULA iterations per launch (lmc_step_rows_pair.hip) where that kernel covers the configuration and the launch is large enough for its
     // long bands: x_{k+2} goes to a third array (neighbouring bands re-read x_k), x_{k+1} is stored only when the moment accumulators keep it.
-    // LMC_ROWS_PAIR: 0 = never, 2 = wherever covered (tests), default = where it pays (n_chains * H >= 2^17).  Read per call.
+    // lmc_problem.iterations_per_launch / LMC_ROWS_PAIR: 0 = never, 2 = wherever covered (tests), default = where it pays (n_chains * H >= 2^17).
     if (pair_mode && n_iters - k >= 2 && !noise_dev && !overlap && !graph_ok && !s->tvwarm[0] && !s->rtmp && s->prob.ncvx_kind == LMC_NCVX_NONE &&
         (variant_of(s->prob) == 0 || variant_of(s->prob) == 6) && (pair_mode == 2 || (long long)s->C * s->prob.H >= (1 << 17))) {
       lmc::StepArgs A = s->base;
@@ -1289,7 +1448,7 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
         if (keep_out) { HIP_TRY(lmc::launch_moments(s->xspare, s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
         std::swap(s->x[s->cur], s->xspare);        // x[cur] = x_{k+2}; the array that held x_k is the spare now
         for (int i = 0; i < 2; ++i)                // captured graphs hold the old pointers
-          if (s->gexec[i]) { hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
+          if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
         s->iteration += 2;
         ++s->last_launches;
         ++k;
@@ -1336,7 +1495,7 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     A.noise = noise_dev ? noise_dev + (size_t)k * per_iter : nullptr;
     sanitize_pointers(A);
     if (s->prob.ncvx_kind == LMC_NCVX_ME_TV) {   // inner prox of the Moreau-envelope term, then the fused step
-      int rc = me_tv_prox(s->prob, A.x_in, s->extra, s->C, s->tvstate[0], s->tvstate[1], st);
+      int rc = me_tv_prox(s->prob, A.x_in, s->extra, s->C, s->tvstate[0], s->tvstate[1], st, &s->rt_me);
       if (rc) return rc;
       A.extra = s->extra;
       A.extra_coef = -s->prob.ncvx_lambda / s->prob.ncvx_gamma;
@@ -1348,13 +1507,22 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches], st));
     const char* kname = nullptr;
     hipError_t e;
+    bool stepped = false;
+    if (s->rt_tv.kc && A.prior_kind == LMC_PRIOR_TV_ISO) {   // early exit of the TV prox decided on the device: inside the fused launch, or the prox alone first
+      const int rc = tv_prior_rt(s->prob, s->epsg * s->gamma, A, s->rt_tv, s->pxbuf, s->tvstate[0], s->tvstate[1], st);
+      if (rc < 0) return rc;
+      if (rc == 2) return fail(LMC_E_STATE, "the device-side early exit no longer covers this sampler");
+      if (rc == 1) { stepped = true; kname = "myula_step_pipe_kernel(per-chain exit)"; }
+    }
     if (s->rtmp && A.prior_kind == LMC_PRIOR_TV_ISO) {   // early-exit TV prox first (exact pass-by-pass path), consumed as a ready-made prox
       int rc = tv_prox_rtol(s->prob, s->epsg * s->gamma, A.x_in, s->pxbuf, s->rtmp, s->robj, s->rflag, s->C, s->tvstate[0], s->tvstate[1], st);
       if (rc) return rc;
       A.prior_kind = LMC_PRIOR_NONE;
       A.prox_ext = s->pxbuf;
     }
-    if (s->tvwarm[0]) {     // warm-started TV prox: the dual of the previous iteration in, this iteration's out
+    if (stepped) {
+      e = hipSuccess;
+    } else if (s->tvwarm[0]) {     // warm-started TV prox: the dual of the previous iteration in, this iteration's out
       A.tv_in = s->tvwarm[s->wcur];
       A.tv_out = s->tvwarm[s->wcur ^ 1];
       e = lmc::launch_step_pipe_warm(A, st);
@@ -1399,7 +1567,7 @@ int lmc_mymala_create(const lmc_myula_config* cfg, lmc_sampler** out) {
   lmc_sampler* s = *out;
   *out = nullptr;
   if (s->tvwarm[0]) { lmc_sampler_destroy(s); return fail(LMC_E_UNSUPPORTED, "MYMALA needs a proposal mean that is a function of x alone: tv_warm is not allowed"); }
-  if (s->rtmp) { lmc_sampler_destroy(s); return fail(LMC_E_UNSUPPORTED, "MYMALA with tv_rtol > 0 is not built (use the fixed-count prox, tv_rtol = 0)"); }
+  if (s->rtmp || s->rt_tv.kc) { lmc_sampler_destroy(s); return fail(LMC_E_UNSUPPORTED, "MYMALA with tv_rtol > 0 is not built (use the fixed-count prox, tv_rtol = 0)"); }
   s->kind = 2;
   const size_t nbytes = sizeof(float) * (size_t)s->C * s->prob.H * s->prob.W;
   hipError_t e = hipMalloc(&s->mx, nbytes);
@@ -1509,8 +1677,7 @@ static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, h
   // pixel, bit-identical -- tests/test_gpu_ulpda.py).  Measured at 512 x 512 x 1024 on one box, alternating: 5.61 / 5.61 ms per iteration fused
   // against 5.57 / 5.66 ms with the two passes -- the neighbour recomputation costs what the 8 B save; left off.  Inside one call only
   // (k + 1 < n_iters): between calls the caller may change the steps, the state or the dual.
-  const char* dr_env = getenv("LMC_ULPDA_DUAL_RHS");
-  const bool fuse_dr = dr_env && atoi(dr_env) != 0 && !s->gfirst && !fuse_fd && s->ydual2 && s->prob.ncvx_kind == LMC_NCVX_NONE &&
+  const bool fuse_dr = s->pol_ulpda_dual_rhs && !s->gfirst && !fuse_fd && s->ydual2 && s->prob.ncvx_kind == LMC_NCVX_NONE &&
                        lmc::ulpda_dual_rhs_supported(H, W);
   s->rhs_ready = false;
   for (int k = 0; k < n_iters; ++k) {
@@ -1524,7 +1691,7 @@ static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, h
       HIP_TRY(lmc::ulpda_ncvx_rhs(s->ctmp, s->htb, s->rhs, C, H, W, s->tau * s->prob.ncvx_lambda, s->prob.ncvx_gamma, ts, st));
     } else if (s->prob.ncvx_kind == LMC_NCVX_ME_TV) {   // x += tau*lamda/gamma (x - prox_{gamma TV}(x))  (algs.py:221-223)
       HIP_TRY(lmc::ulpda_rhs(x, s->ydual, s->z, nullptr, s->ctmp, C, H, W, s->tau, ts, st));
-      int rc = me_tv_prox(s->prob, s->ctmp, s->extra, C, s->tvstate[0], s->tvstate[1], st);
+      int rc = me_tv_prox(s->prob, s->ctmp, s->extra, C, s->tvstate[0], s->tvstate[1], st, &s->rt_me);
       if (rc) return rc;
       HIP_TRY(lmc::ulpda_me_rhs(s->ctmp, s->extra, s->htb, s->rhs, C, H, W, s->tau * s->prob.ncvx_lambda / s->prob.ncvx_gamma, ts, st));
     } else if (s->rhs_ready && s->rhs_tau == s->tau && s->rhs_ts == ts) {
@@ -1624,7 +1791,8 @@ int lmc_ulpda_create(const lmc_ulpda_config* cfg, lmc_sampler** out) {
   hipError_t e = hipSuccess;
   auto alloc = [&](float** p, size_t count) { if (e == hipSuccess) e = hipMalloc(p, sizeof(float) * count); if (e == hipSuccess) e = hipMemset(*p, 0, sizeof(float) * count); };
   alloc(&s->x[0], n); alloc(&s->xhat, n); alloc(&s->ydual, 2 * n); alloc(&s->uw, n); alloc(&s->rhs, n);
-  if (!s->gfirst && s->prob.ncvx_kind == LMC_NCVX_NONE && lmc::ulpda_dual_rhs_supported(s->prob.H, s->prob.W)) alloc(&s->ydual2, 2 * n);
+  s->pol_ulpda_dual_rhs = env_int("LMC_ULPDA_DUAL_RHS", 0) != 0;     // read once, here
+  if (s->pol_ulpda_dual_rhs && !s->gfirst && s->prob.ncvx_kind == LMC_NCVX_NONE && lmc::ulpda_dual_rhs_supported(s->prob.H, s->prob.W)) alloc(&s->ydual2, 2 * n);
   if (!s->gfirst && lmc::ulpda_finish_dual_supported(s->prob.H, s->prob.W) && getenv("LMC_ULPDA_FUSE") && atoi(getenv("LMC_ULPDA_FUSE")))
     alloc(&s->x[1], n);     // ping-pong target of the fused finish + dual pass (opt-in, see ulpda_step)
   if (s->noise_mode == LMC_NOISE_PHILOX) alloc(&s->xi, n);
@@ -1744,6 +1912,20 @@ int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_lau
 }
 
 const char* lmc_sampler_kernel_name(const lmc_sampler* s) { return s ? s->kernel_name.c_str() : ""; }
+
+int lmc_sampler_tv_exit_stats(lmc_sampler* s, int32_t which, int32_t* passes_dev, uint64_t* reruns_host, void* stream) {
+  if (!s || (which != 0 && which != 1)) return fail(LMC_E_INVALID, "bad arguments");
+  DeviceGuard dg(s->device);
+  RtState& rt = which == 0 ? s->rt_tv : s->rt_me;
+  if (!rt.kc) return fail(LMC_E_STATE, "this sampler does not run the device-side early exit for that prox (tv_rtol / ncvx_rtol = 0, or the pass-by-pass path)");
+  hipStream_t st = S(stream);
+  if (passes_dev) HIP_TRY(hipMemcpyAsync(passes_dev, rt.pred, sizeof(int) * (size_t)s->C, hipMemcpyDeviceToDevice, st));
+  unsigned long long r[3] = {0, 0, 0};
+  if (reruns_host) HIP_TRY(hipMemcpyAsync(r, rt.reruns, sizeof r, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (reruns_host) for (int i = 0; i < 3; ++i) reruns_host[i] = r[i];
+  return LMC_OK;
+}
 
 // ---- multi-GPU: the one collective of the path -----------------------------------------------------------------
 // RCCL is reached through dlopen so that the library (and every single-GPU use) does not depend on it.  When the host process has

@@ -77,6 +77,15 @@ struct StepArgs {
   // (iterations `iteration` and `iteration + 1`; x_out <- x_{k+2}); x_mid (may be NULL, may be x_in itself: the update is block-local) <- x_{k+1}
   int fused_iters;
   float* x_mid;
+  // pipe kernel, RT instantiations only: per-chain early exit of the TV prox (pyproximal.TV's rtol; lmc_problem.tv_rtol / ncvx_rtol).  A chain's
+  // workgroup runs rt_kc[c] dual updates in all (counted over the links of a chained prox; this launch holds updates rt_base + 1 .. rt_base + K),
+  // the later stages pass the dual through; it returns at once when rt_kc[c] <= rt_base (the chain left in an earlier link, or needs no run:
+  // rt_kc[c] < 0).  By-products: the primal objective 0.5 ||x - sol_j||^2 + gamma TV(sol_j) of every iterate formed -- stage g adds that of
+  // its input iterate to rt_obj[c][g - 1], the combine wave that of the iterate it returns to rt_obj[c][rt_kc[c]] (unless that is rt_total,
+  // the iterate returned untested).  fp64 sums; rt_obj must be zero where this launch adds.
+  const int* rt_kc;
+  double* rt_obj;
+  int rt_stride, rt_base, rt_total;
 };
 
 constexpr uint32_t kPhiloxStream = 0x4C4D4301u;  // counter word 3 (noise field)

@@ -41,6 +41,9 @@ hipError_t launch_bump_u32(uint32_t* p, uint32_t by, hipStream_t st);
 hipError_t launch_tv_objective(const float* x, const float* sol, int64_t n, int H, int W, float gam, const int* flag, double* obj, hipStream_t st);
 hipError_t launch_tv_rtol_decide(int64_t n, double* prev, double* cur, int* flag, int pass, double rtol, int* n_active, hipStream_t st);
 hipError_t launch_tv_rtol_select(const float* tmp, float* sol, const int* flag, int pass, int64_t n, size_t img, hipStream_t st);
+// the early exit without leaving the device (speculate / verify / re-run; lmc_ops.hip, lmc_capi.hip: tv_prox_rt)
+hipError_t launch_tv_rt_begin(int64_t n, const int* pred, int* kc, double* obj, int stride, int niter, hipStream_t st);
+hipError_t launch_tv_rt_decide(int64_t n, int* kc, int* pred, double* obj, int stride, int niter, double rtol, unsigned long long* reruns, hipStream_t st);
 int hbm_copy_probe_shapes();
 hipError_t launch_hbm_copy_probe(const float* x, float* y, size_t n_floats, int shape, hipStream_t st);
 hipError_t launch_noise(float* out, int C, int H, int W, uint32_t key0, uint32_t key1, uint32_t iteration,
@@ -72,6 +75,10 @@ hipError_t launch_step_pipe(StepArgs a, hipStream_t st, float* state0 = nullptr,
 // warm-started TV prox: a.tv_in / a.tv_out = [C][2][H][W] projected dual of the previous / this MYULA iteration
 bool pipe_warm_supported(const StepArgs& a);
 hipError_t launch_step_pipe_warm(StepArgs a, hipStream_t st);
+// per-chain early exit of the TV prox (lmc_step_pipe_rt.hip): a.tv.niter in 1 .. 60 dual updates at most, a.rt_kc / rt_obj / rt_stride set by the
+// caller; more than 10: a chain of links through state0 / state1 ([C][4][H][W]), pure prox only (no data term, no noise)
+bool pipe_rt_supported(const StepArgs& a);
+hipError_t launch_step_pipe_rt(StepArgs a, hipStream_t st, float* state0 = nullptr, float* state1 = nullptr);
 // split streaming variant: the same pipeline over two wave groups (lmc_step_split.hip)
 bool split_supported(const StepArgs& a);
 hipError_t launch_step_split(StepArgs a, hipStream_t st);

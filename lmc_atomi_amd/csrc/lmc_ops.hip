@@ -779,6 +779,48 @@ hipError_t launch_tv_rtol_select(const float* tmp, float* sol, const int* flag, 
   return hipGetLastError();
 }
 
+// ---- the same early exit without leaving the device (lmc_capi.hip: tv_prox_rt): speculate, verify, re-run -------------------------------------
+// A chain's prox runs with a PREDICTED number of dual updates k (the pass it left in at the previous call: the objective is a sum over the
+// whole image and moves little from one MYULA iterate to the next), fused in the RT instantiations of the pipe kernel, which leave the primal
+// objective of every iterate they form in obj[c][0 .. k].  This kernel replays upstream's test on them, one thread per chain:
+//   the first pass j in 1 .. min(k, niter - 1) with |obj_j - obj_{j-1}| / obj_j < rtol (obj_j > 0) is the pass e the chain leaves in;
+//   e == k, or no such pass and k == niter (the iterate after niter updates is returned untested): the run was the reference's -- done;
+//   e <  k: re-run with e updates (exact);   no such pass and k < niter: re-run with all niter updates -- that run's objectives give e exactly.
+// At most three rounds settle every chain (prediction, full, exact); kc[c] = -1 marks a settled chain, whose workgroups return at once.
+__global__ void tv_rt_begin_kernel(int64_t n, const int* __restrict__ pred, int* __restrict__ kc, double* __restrict__ obj, int stride, int niter) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const int k = pred[c];
+  kc[c] = (k >= 1 && k <= niter) ? k : niter;
+  for (int j = 0; j <= niter; ++j) obj[c * stride + j] = 0.0;
+}
+__global__ void tv_rt_decide_kernel(int64_t n, int* __restrict__ kc, int* __restrict__ pred, double* __restrict__ obj, int stride, int niter, double rtol,
+                                    unsigned long long* __restrict__ reruns) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const int k = kc[c];
+  if (k < 0) return;
+  double* o = obj + c * stride;
+  int e = 0;
+  const int jmax = k < niter - 1 ? k : niter - 1;
+  for (int j = 1; j <= jmax; ++j) {
+    const double rel = o[j] > 0.0 ? fabs(o[j] - o[j - 1]) / o[j] : 2.0 * rtol;
+    if (rel < rtol) { e = j; break; }
+  }
+  if (e == k || (e == 0 && k == niter)) { pred[c] = k; kc[c] = -1; return; }
+  kc[c] = e > 0 ? e : niter;
+  for (int j = 0; j <= niter; ++j) o[j] = 0.0;
+  if (reruns) atomicAdd(reruns, 1ull);
+}
+hipError_t launch_tv_rt_begin(int64_t n, const int* pred, int* kc, double* obj, int stride, int niter, hipStream_t st) {
+  hipLaunchKernelGGL(tv_rt_begin_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, n, pred, kc, obj, stride, niter);
+  return hipGetLastError();
+}
+hipError_t launch_tv_rt_decide(int64_t n, int* kc, int* pred, double* obj, int stride, int niter, double rtol, unsigned long long* reruns, hipStream_t st) {
+  hipLaunchKernelGGL(tv_rt_decide_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, n, kc, pred, obj, stride, niter, rtol, reruns);
+  return hipGetLastError();
+}
+
 // *p += by (one thread): the device-side iteration base of a replayed hipGraph of MYULA iterations
 __global__ void bump_u32_kernel(uint32_t* p, uint32_t by) { *p += by; }
 hipError_t launch_bump_u32(uint32_t* p, uint32_t by, hipStream_t st) {

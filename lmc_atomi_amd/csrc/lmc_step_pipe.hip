@@ -8,7 +8,7 @@ namespace lmc {
 int centred_blur_taps(const StepArgs& a, float* uc, float* vc);   // lmc_step_rows.hip
 
 // image geometry and data term the kernel covers (whatever the number of dual iterations)
-static bool pipe_geometry_ok(const StepArgs& a) {
+bool pipe_geometry_ok(const StepArgs& a) {
   if (a.prior_kind != LMC_PRIOR_TV_ISO || a.prox_ext) return false;
   // 8 (4) pixels per lane above (up to) 256 columns; narrower than 129 columns half the lanes idle and the split kernel wins.  Any width:
   // rows that are not 16-byte aligned (W % 4 != 0) use dword-aligned 16-byte accesses and per-pixel masks, images wider than 512 columns run as column
@@ -52,7 +52,7 @@ bool pipe_warm_supported(const StepArgs& a) {
   return pipe_geometry_ok(a);
 }
 
-static int pipe_taps(StepArgs& a) {
+int pipe_taps(StepArgs& a) {
   int KT = 0;
   if (a.data_kind == LMC_DATA_BLUR) {
     float uc[kMaxBlur] = {0}, vc[kMaxBlur] = {0};

@@ -109,25 +109,43 @@ __device__ __forceinline__ v2f pipe_ncr(const PipeCr<NP>& c, int i) {
   else return c.ncrv[i];
 }
 
-template <int NP, bool LASTLANE = true>
+// Objective by-products of a stage (RT instantiations: the per-chain early exit of the TV prox).  The stage forms the iterate sol = x - gam div(rr, ss)
+// on row a and has the one on row b = a - 1 from the previous tick: the pieces of its primal objective 0.5 ||x - sol||^2 + gam TV(sol) are sums of
+// what the stage computes anyway -- x - sol = gam T with T = div(rr, ss) on row a, and the forward differences of sol on row b (masked like the dual
+// step: none across the last row / column).  sq += sum T^2 (row a), tv += sum |grad sol| (row b), fp32 per row; the caller folds rows into fp64.
+struct StageObj { v2f sq, tv; };
+template <int NP>
+struct ObjMask { float md; v2f mlast; };     // 1 / 0: the row below exists; the column to the right of the lane's last pair exists
+
+template <int NP, bool LASTLANE = true, bool OBJ = false>
 __device__ __forceinline__ void pipe_stage(const v2f (&xa)[NP], const v2f (&r1)[NP], const v2f (&s1)[NP], const DualRow<NP>& in0,
                                            v2f (&solb)[NP], float gam, float cdown, const PipeCr<NP>& cr, float beta,
-                                           DualRow<NP>& out) {
+                                           DualRow<NP>& out, StageObj* ob = nullptr, const ObjMask<NP>* om = nullptr) {
   v2f sol[NP];
   const float ssl0 = dpp_left0(s1[NP - 1].y);
   const v2f ngam = pk_set(-gam), ncd = pk_set(-cdown), vb = pk_set(beta);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const v2f ssl = v2f{i == 0 ? ssl0 : s1[i - 1].y, s1[i].x};
-    sol[i] = pk_fma(ngam, (r1[i] - in0.rr[i]) + (s1[i] - ssl), xa[i]);
+    const v2f T = (r1[i] - in0.rr[i]) + (s1[i] - ssl);
+    sol[i] = pk_fma(ngam, T, xa[i]);
+    if constexpr (OBJ) ob->sq = i == 0 ? T * T : pk_fma(T, T, ob->sq);
   }
   const float solr_last = dpp_right0(solb[0].x);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const v2f solr = v2f{solb[i].y, i == NP - 1 ? solr_last : solb[i + 1].x};
     const v2f ncr = pipe_ncr<NP, LASTLANE>(cr, i);
-    const v2f r = pk_fma(ncd, sol[i] - solb[i], in0.rr[i]);
-    const v2f s = pk_fma(ncr, solr - solb[i], in0.ss[i]);
+    const v2f dxv = sol[i] - solb[i], dyv = solr - solb[i];
+    if constexpr (OBJ) {
+      static_assert(!OBJ || LASTLANE, "objective by-products: rows whose last column is a lane's last pixel");
+      const v2f dxm = dxv * pk_set(om->md), dym = i == NP - 1 ? dyv * om->mlast : dyv;
+      const v2f n = pk_fma(dxm, dxm, dym * dym);
+      const v2f nr = v2f{__builtin_amdgcn_sqrtf(n.x), __builtin_amdgcn_sqrtf(n.y)};
+      ob->tv = i == 0 ? nr : ob->tv + nr;
+    }
+    const v2f r = pk_fma(ncd, dxv, in0.rr[i]);
+    const v2f s = pk_fma(ncr, dyv, in0.ss[i]);
     const v2f n2 = pk_fma(r, r, s * s);
     // min(1, rsq(n2)) == rsq(max(n2, 1)) bit for bit (rsq is monotone, rsq(1) = 1); written as a [0,1] clamp it folds into the
     // output modifier of v_rsq_f32 and the v_max disappears
@@ -144,17 +162,25 @@ __device__ __forceinline__ void pipe_stage(const v2f (&xa)[NP], const v2f (&r1)[
 
 // Stage 1 of a launch that starts from the zero dual state: (rr, ss, p, q)^0 = 0, so sol^1 = x and the differences with the previous
 // iterate vanish.  Bit-identical to pipe_stage() fed with zeros (x - 0 = x, fma(c, d, 0) = c*d), at ~60 % of its instructions.
-template <int NP, bool LASTLANE = true>
+template <int NP, bool LASTLANE = true, bool OBJ = false>
 __device__ __forceinline__ void pipe_stage_first(const v2f (&xa)[NP], v2f (&solb)[NP], float cdown, const PipeCr<NP>& cr, float beta,
-                                                 DualRow<NP>& out) {
+                                                 DualRow<NP>& out, StageObj* ob = nullptr, const ObjMask<NP>* om = nullptr) {
   const float solr_last = dpp_right0(solb[0].x);
   const v2f ncd = pk_set(-cdown), vb = pk_set(beta);
+  if constexpr (OBJ) ob->sq = pk_set(0.f);       // sol^0 = x
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const v2f solr = v2f{solb[i].y, i == NP - 1 ? solr_last : solb[i + 1].x};
     const v2f ncr = pipe_ncr<NP, LASTLANE>(cr, i);
-    const v2f r = ncd * (xa[i] - solb[i]);
-    const v2f s = ncr * (solr - solb[i]);
+    const v2f dxv = xa[i] - solb[i], dyv = solr - solb[i];
+    if constexpr (OBJ) {
+      const v2f dxm = dxv * pk_set(om->md), dym = i == NP - 1 ? dyv * om->mlast : dyv;
+      const v2f n = pk_fma(dxm, dxm, dym * dym);
+      const v2f nr = v2f{__builtin_amdgcn_sqrtf(n.x), __builtin_amdgcn_sqrtf(n.y)};
+      ob->tv = i == 0 ? nr : ob->tv + nr;
+    }
+    const v2f r = ncd * dxv;
+    const v2f s = ncr * dyv;
     const v2f n2 = pk_fma(r, r, s * s);
     const v2f inv = v2f{__builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(n2.x), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rsqf(n2.y), 0.f, 1.f)};
     const v2f pn = r * inv, qn = s * inv;
@@ -236,9 +262,14 @@ __host__ __device__ constexpr int pipe_halo(int K, int KT, int PXL) {
 // link state -- a template parameter because the L wave's prefetch registers for the state rows set the kernel's VGPR count.
 // AL: image rows start on 16-byte boundaries (W % 4 == 0): float4 global accesses; AL = false (any W): pixel-by-pixel accesses with per-pixel bounds
 // (instantiated for K = 10 only: the reference's 667 x 877 image with niter_tv = 10 and the 10-iteration links of its ME-TV term).
-template <int K, int PXL, int KT, bool CHAIN = false, bool WARM = false, bool AL = true>
+// RT: per-chain early exit of the prox (StepArgs::rt_*; pyproximal.TV's rtol): the chain of this workgroup runs kc <= K live stages, the stages after
+// them pass (rr, ss) through unchanged -- a delay line with the live stages' timing, so the combine wave forms x - gamma div(rr^kc, ss^kc) -- and every
+// iterate formed leaves its primal objective behind.  In a chained launch the link a chain leaves in does its combine; the links before it only
+// advance the dual state, the ones after it return at once.
+template <int K, int PXL, int KT, bool CHAIN = false, bool WARM = false, bool AL = true, bool RT = false>
 __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM ? LMC_WARM_MIN_WAVES : 1) : 2) void myula_step_pipe_kernel(const StepArgs A) {
   static_assert(!WARM || CHAIN, "the warm dual uses the state hand-over of the chained launches");
+  static_assert(!RT || (AL && !WARM && (K & 1) == 0), "per-chain exit: aligned rows, cold start, even K");
   using G = PipeGeom<K>;
   using L = PipeLds<K, PXL, CHAIN>;
   constexpr int D = G::D, E = G::E, RB = G::RB, NT = G::NT, BW = L::BW, HW = KT > 0 ? (KT - 1) / 2 : 0;
@@ -249,6 +280,15 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int chain = blockIdx.x;
   const int H = A.H, W = A.W;
+  // per-chain exit: live stages of this launch, and whether this link only advances the dual state of this chain (it leaves in a later link)
+  int kc = K;
+  bool state_only = CHAIN && A.tv_state_only;
+  if constexpr (RT) {
+    const int kc_g = __builtin_amdgcn_readfirstlane(A.rt_kc[chain]);
+    if (kc_g <= A.rt_base) return;                   // whole workgroup, before any barrier: left in an earlier link, or no run needed
+    kc = min(kc_g - A.rt_base, K);
+    state_only = CHAIN && kc_g > A.rt_base + K;
+  }
   // column strip of this workgroup (blockIdx.y; one strip = the whole row when W <= 64 PXL): c0 is a GLOBAL column, LDS rows are indexed by lane
   constexpr int HALO = pipe_halo(K, KT, PXL);
   const int strip = blockIdx.y;
@@ -503,8 +543,13 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     constexpr bool warm = WARM;
     const float* const hin = from_state ? lds + L::o_hand0 : hout - 8 * BW;   // the previous wave's / the previous link's state
     constexpr int nof = warm ? 2 : 4;                                // fields per pixel of the outgoing state
-    float* const sout = CHAIN && wave == NT && A.tv_out ? A.tv_out + (size_t)chain * nof * img : nullptr;
+    float* const sout = CHAIN && wave == NT && A.tv_out && (!RT || state_only) ? A.tv_out + (size_t)chain * nof * img : nullptr;
     constexpr int NP = PXL / 2;
+    const bool live1 = !RT || k1 <= kc, live2 = !RT || k2 <= kc;      // wave-uniform; live stages are a prefix: live2 implies live1
+    ObjMask<NP> om;
+    om.md = 0.f;
+    om.mlast = v2f{1.f, (c0 + PXL - 1 == W - 1) ? 0.f : 1.f};
+    double osq1 = 0.0, otv1 = 0.0, osq2 = 0.0, otv2 = 0.0;            // RT: objective sums of the iterates stages k1 / k2 form (fp64 over rows)
     DualRow<NP> inb[2], o1[2];
     v2f sol1[NP], sol2[NP];
     v2f xk[2][NP];        // x rows read for stage k1 (row a1 = a2 + 2), reused by stage k2 two ticks later: one ring read per tick
@@ -520,8 +565,12 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     }
     // the wave's last stage hands its output (dual state of row `brow`) to the next wave / the combine wave, and, in the last wave of a
     // chained launch, to HBM for the next link (all four fields) or the next MYULA iteration (warm dual: p, q)
-    auto emit = [&](const DualRow<NP>& out, const int P, const int brow) __attribute__((always_inline)) {
-      if (!CHAIN || wave < NT) {
+    auto emit = [&](const DualRow<NP>& out, const int P, const int brow, const bool live) __attribute__((always_inline)) {
+      if (RT && !live) {             // pass-through: only (rr, ss) travel on (the combine wave's operands); same slots in both hand-off layouts
+        float* hb = hout + P * ((!CHAIN || wave < NT) ? 4 : 2) * BW;
+        pairs_store<NP>(hb, lane, out.rr);
+        pairs_store<NP>(hb + BW, lane, out.ss);
+      } else if (!CHAIN || wave < NT) {
         float* hb = hout + P * 4 * BW;
 #ifdef LMC_EXP_NO_HSTORE     // timing experiment: the hand-off stores never execute (results are wrong), the arithmetic stays alive
         if (A.tv.niter == 12345)
@@ -565,8 +614,16 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       if constexpr (!SINGLE) {   // stage k2 on row a2: inputs are this wave's stage k1, one tick (row a2) and two ticks (row a2-1) old
         const float cdown = ((unsigned)(a2 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
         DualRow<NP> out;
-        pipe_stage<NP, AL>(xk[P], o1[P ^ 1].rr, o1[P ^ 1].ss, o1[P], sol2, gam, cdown, crc, beta2, out);
-        emit(out, P, a2 - 1);
+        if (live2) {
+          StageObj ob;
+          om.md = cdown != 0.f ? 1.f : 0.f;
+          pipe_stage<NP, AL, RT>(xk[P], o1[P ^ 1].rr, o1[P ^ 1].ss, o1[P], sol2, gam, cdown, crc, beta2, out, &ob, &om);
+          if constexpr (RT) { osq2 += (double)(ob.sq.x + ob.sq.y); otv2 += (double)(ob.tv.x + ob.tv.y); }
+        } else {                 // pass-through: the state of row a2 - 1 as stage k1 left it
+#pragma unroll
+          for (int k = 0; k < NP; ++k) { out.rr[k] = o1[P].rr[k]; out.ss[k] = o1[P].ss[k]; }
+        }
+        emit(out, P, a2 - 1, live2);
       }
       {   // stage k1 on row a1: inputs from the previous wave's hand-off (row a1) and the one read a tick earlier (row a1-1)
         if constexpr (!FIRST) {
@@ -577,21 +634,41 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
             if (from_state && warm) {     // warm dual: the state IS the projected iterate (beta_1 = 0 makes its role as p_old void)
 #pragma unroll
               for (int k = 0; k < NP; ++k) { inb[P].p[k] = inb[P].rr[k]; inb[P].q[k] = inb[P].ss[k]; }
-            } else {
+            } else if (live1) {           // (a pass-through stage moves rr, ss only)
               pairs_load<NP>(inb[P].p, hb + 2 * BW, lane);
               pairs_load<NP>(inb[P].q, hb + 3 * BW, lane);
             }
           }
         }
-        pairs_load<NP>(xk[P], ring_row(a1), lane);      // read two ticks ago as row a1 = this tick's a2: consumed above
-        const float cdown = ((unsigned)(a1 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
-        if constexpr (FIRST) pipe_stage_first<NP, AL>(xk[P], sol1, cdown, crc, beta1, o1[P]);
-        else pipe_stage<NP, AL>(xk[P], inb[P].rr, inb[P].ss, inb[P ^ 1], sol1, gam, cdown, crc, beta1, o1[P]);
-        if constexpr (SINGLE) emit(o1[P], P, a1 - 1);
+        if (live1) {
+          pairs_load<NP>(xk[P], ring_row(a1), lane);      // read two ticks ago as row a1 = this tick's a2: consumed above
+          const float cdown = ((unsigned)(a1 - 1) >= (unsigned)(H - 1)) ? 0.f : cstep;
+          StageObj ob;
+          om.md = cdown != 0.f ? 1.f : 0.f;
+          if constexpr (FIRST) pipe_stage_first<NP, AL, RT>(xk[P], sol1, cdown, crc, beta1, o1[P], &ob, &om);
+          else pipe_stage<NP, AL, RT>(xk[P], inb[P].rr, inb[P].ss, inb[P ^ 1], sol1, gam, cdown, crc, beta1, o1[P], &ob, &om);
+          if constexpr (RT) { osq1 += (double)(ob.sq.x + ob.sq.y); otv1 += (double)(ob.tv.x + ob.tv.y); }
+        } else {                 // pass-through: the state of row a1 - 1, read one tick ago
+#pragma unroll
+          for (int k = 0; k < NP; ++k) { o1[P].rr[k] = inb[P ^ 1].rr[k]; o1[P].ss[k] = inb[P ^ 1].ss[k]; }
+        }
+        if constexpr (SINGLE) emit(o1[P], P, a1 - 1, live1);
       }
       PIPE_TICK_SYNC();
     };
     for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
+    if constexpr (RT) {          // objectives of the iterates this wave's live stages formed: sol^{g-1} in stage g = rt_base + k
+      const double dg = (double)gam;
+      double* const ob = A.rt_obj + (size_t)chain * A.rt_stride + A.rt_base;
+      if (live1) {
+        const double tot = wave_sum(0.5 * dg * dg * osq1 + dg * otv1);
+        if (lane == 0) unsafeAtomicAdd(ob + (k1 - 1), tot);
+      }
+      if (!SINGLE && live2) {
+        const double tot = wave_sum(0.5 * dg * dg * osq2 + dg * otv2);
+        if (lane == 0) unsafeAtomicAdd(ob + (k2 - 1), tot);
+      }
+    }
     };   // t_role
     constexpr bool kOdd = (K & 1) != 0;
     bool ran = false;
@@ -618,7 +695,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       constexpr int U = decltype(uu)::value;
       constexpr int NI = ((U - D) % 4 + 4) % 4;        // == o & 3  (t = 4m + U)
       const int o = t - D;
-      if (A.noise_mode == LMC_NOISE_PHILOX && !(CHAIN && A.tv_state_only)) {
+      if (A.noise_mode == LMC_NOISE_PHILOX && !state_only) {
         const int qn = ((o - NI) >> 2) + 1;             // quad row-group being prepared (o - NI is a multiple of 4)
         if (qn >= 0 && 4 * qn < H) {
           float* const sl = slab + (qn & 1) * (4 * PXL * 64);
@@ -645,6 +722,13 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     float crr[2][PXL], xprev[PXL];
 #pragma unroll
     for (int k = 0; k < PXL; ++k) crr[0][k] = crr[1][k] = xprev[k] = 0.f;
+    // RT: primal objective of the iterate this wave returns, sol^kc (the one the exit test of pass kc looks at; not needed when kc is the
+    // last pass, whose iterate is returned untested): sum of squared divergences row by row, |grad sol| of row o - 1 once row o is known
+    const bool want_obj = RT && !state_only && A.rt_base + kc < A.rt_total;
+    double osq = 0.0, otv = 0.0;
+    float pprev[RT ? PXL : 1];
+#pragma unroll
+    for (int k = 0; k < (RT ? PXL : 1); ++k) pprev[k] = 0.f;
     // rows of the ME-TV term's prox image (A.extra), requested three ticks ahead of their use (slot tick & 3): a load issued at
     // its point of use would expose an HBM access per tick
     float exq[4][PXL];
@@ -663,7 +747,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       constexpr int U = decltype(uu)::value, P = U & 1;
       constexpr int NI = ((U - D) % 4 + 4) % 4;        // == o & 3  (t = 4m + U)
       const int o = t - D;
-      if (CHAIN && A.tv_state_only) { PIPE_TICK_SYNC(); return; }     // this link only advances the dual state
+      if (state_only) { PIPE_TICK_SYNC(); return; }     // this link only advances the dual state (of this chain)
       if (A.extra) {
         const int r3 = o + 3;
         gload_raw<PXL>(exq[(U + 3) & 3], A.extra + (size_t)chain * img + (size_t)min(max(r3, 0), H - 1) * W, c0, W, al);
@@ -679,10 +763,31 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
         for (int j = 0; j < PXL; ++j) gv[j] = 0.f;
       }
       const float ssl0 = dpp_left0(css[PXL - 1]);
+      float dvs = 0.f;
 #pragma unroll
       for (int j = 0; j < PXL; ++j) {
         const float ssl = j == 0 ? ssl0 : css[j - 1];
-        prox[j] = fmaf(-gam, (crr[P][j] - crr[P ^ 1][j]) + (css[j] - ssl), xo[j]);
+        const float dv = (crr[P][j] - crr[P ^ 1][j]) + (css[j] - ssl);
+        prox[j] = fmaf(-gam, dv, xo[j]);
+        if constexpr (RT) dvs = fmaf(dv, dv, dvs);
+      }
+      if constexpr (RT) {
+        if (want_obj && o >= 0 && o < H) {
+          osq += (double)dvs;
+          if (o >= 1) {               // row o - 1: the row below it is this one
+            const float pr_last = dpp_right0(pprev[0]);
+            float tvs = 0.f;
+#pragma unroll
+            for (int j = 0; j < PXL; ++j) {
+              const float dx = prox[j] - pprev[j];
+              const float dy = (c0 + j + 1 < W) ? (j == PXL - 1 ? pr_last : pprev[j + 1]) - pprev[j] : 0.f;
+              tvs += __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
+            }
+            otv += (double)tvs;
+          }
+#pragma unroll
+          for (int j = 0; j < PXL; ++j) pprev[j] = prox[j];
+        }
       }
       if (A.ncvx_kind == LMC_NCVX_MC_TV) {   // - lambda * A^T(A x / max(|A x|, gamma))  (algs.py:273-277, 291), added to the gradient
         // rows o-1 (kept in registers: its ring slot is being overwritten by row t this very tick), o, o+1 (ring)
@@ -752,6 +857,18 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       const double tot = wave_sum(gacc);
       if (lane == 0) unsafeAtomicAdd(&A.g_out[chain], (double)A.g_scale * tot);
     }
+    if constexpr (RT) {
+      if (want_obj) {               // the last image row: no row below it, horizontal differences only
+        const float pr_last = dpp_right0(pprev[0]);
+        float tvs = 0.f;
+#pragma unroll
+        for (int j = 0; j < PXL; ++j) tvs += (c0 + j + 1 < W) ? fabsf((j == PXL - 1 ? pr_last : pprev[j + 1]) - pprev[j]) : 0.f;
+        otv += (double)tvs;
+        const double dg = (double)gam;
+        const double tot = wave_sum(0.5 * dg * dg * osq + dg * otv);
+        if (lane == 0) unsafeAtomicAdd(A.rt_obj + (size_t)chain * A.rt_stride + A.rt_base + kc, tot);
+      }
+    }
   }
 }
 
@@ -759,9 +876,9 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
 template <int K, int PXL, int KT, bool CHAIN = false>
 static constexpr size_t pipe_lds_bytes() { return sizeof(float) * (size_t)PipeLds<K, PXL, CHAIN>::total; }
 
-template <int PXL, int KT, bool CHAIN, int K = 10, bool WARM = false, bool AL = true>
+template <int PXL, int KT, bool CHAIN, int K = 10, bool WARM = false, bool AL = true, bool RT = false>
 static hipError_t pipe_launch_one(const StepArgs& a, hipStream_t st) {
-  auto kern = myula_step_pipe_kernel<K, PXL, KT, CHAIN, WARM, AL>;
+  auto kern = myula_step_pipe_kernel<K, PXL, KT, CHAIN, WARM, AL, RT>;
   constexpr size_t lb = pipe_lds_bytes<K, PXL, KT, CHAIN>();
   static bool attr_set[64] = {};        // per device: the attribute belongs to the function's code object on that device
   int dev = 0;
@@ -808,6 +925,10 @@ static hipError_t pipe_dispatch_k(const StepArgs& a, int KT, hipStream_t st) {
   if (KT == 7) return pipe_launch_one<4, 7, CHAIN, K, WARM>(a, st);
   return pipe_launch_one<4, 0, CHAIN, K, WARM>(a, st);
 }
+
+// lmc_step_pipe.hip: geometry / data term the pipe kernels cover, and the centred taps (returns KT)
+bool pipe_geometry_ok(const StepArgs& a);
+int pipe_taps(StepArgs& a);
 
 // lmc_step_pipe_chain.hip: the CHAIN instantiations (dual state in / out through HBM): links of a chained launch (K = 9, 10) and the
 // warm-started prox (a.tv_warm: K = 1, 2, 3)

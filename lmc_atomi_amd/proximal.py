@@ -104,6 +104,13 @@ class _Problem:
         v = opt.get("step_variant", 0) or 0
         p.step_variant = _capi.VARIANTS.index(v) if isinstance(v, str) else int(v)
         p.implicit_tol = float(opt.get("implicit_tol", data.get("implicit_tol", 0.0)) or 0.0)
+        # ABI 3: early exit of the ME-TV inner prox, which of the two exit paths, launch policy (0 = the library decides)
+        p.ncvx_rtol = float(data.get("ncvx_rtol", 0.0) or 0.0)
+        p.tv_exit_path = int(prior.get("tv_exit_path", 0) or opt.get("tv_exit_path", 0) or 0)
+        p.iterations_per_launch = int(opt.get("iterations_per_launch", 0) or 0)
+        p.moments_overlap = int(opt.get("moments_overlap", 0) or 0)
+        p.moments_bg_workgroups = int(opt.get("moments_bg_workgroups", 0) or 0)
+        p.graph_replay = 1 if opt.get("graph_replay") else 0
         self.c = p
 
     def eval(self, x, a, t, b, pt):
@@ -291,23 +298,26 @@ class TV(ProxOperator):
     Deviations from upstream, both named in DESIGN section 4:
 
     * ``rtol``: pyproximal's per-image early exit on the relative change of the primal objective (its default 1e-4, which the
-      reference's call does not override).  Default here: 0 = off, every image runs ``niter`` dual iterations in ONE fused launch (the
-      fast path; against the reference as configured the trajectory differs by 1.5e-4 rel-L2 and the posterior mean by 8e-5, DESIGN
-      section 4).  ``rtol > 0`` selects the exact pass-by-pass path on the GPU (images leave individually; one launch per loop pass
-      plus one for its objective, a host read of the number of images still iterating after every pass): it reproduces the
-      reference's configured behaviour and costs several times the fast path.
+      reference's call does not override).  Default here: 0 = off, every image runs ``niter`` dual iterations in ONE fused launch (against
+      the reference as configured the trajectory differs by 1.5e-4 rel-L2 and the posterior mean by 8e-5).
+      ``rtol > 0`` reproduces the reference's configured behaviour -- every image leaves in the pass upstream's loop leaves it in:
+      decided on the device without synchronisation where the full-width pipeline covers the image (128 < W <= 512; every chain runs
+      with the pass count it left in at the previous call, the launch leaves the primal objectives of its iterates behind, chains whose
+      prediction was wrong run again), pass by pass elsewhere (``exit_path='passes'`` forces that path: one launch per loop pass plus
+      one for its objective and a host read after every pass).
     * ``lagged_output``: whether upstream's truncated iterate after ``niter`` loop passes reflects ``niter`` or ``niter - 1`` dual
       updates depends on the loop bound of the un-pinned upstream version; ``False`` (default) = ``niter`` updates,
       ``True`` = ``niter - 1`` (one pipeline stage fewer).
     * ``warm`` (build extension, MYULA samplers only): carry the projected dual from one MYULA iteration to the next, ``niter``
       in {1, 2, 3} updates per MYULA iteration ("K in {1,3} warm-dual")."""
 
-    def __init__(self, dims, sigma=1.0, niter=10, rtol=0.0, step=0.125, momentum="unlocbox", lagged_output=False, warm=False):
+    def __init__(self, dims, sigma=1.0, niter=10, rtol=0.0, step=0.125, momentum="unlocbox", lagged_output=False, warm=False, exit_path="auto"):
         super().__init__(None, False)
         self.dims = (int(dims[0]), int(dims[1]))
         self.sigma = float(sigma)
         self.niter = int(niter)
         self.rtol = float(rtol)
+        self.exit_path = {"auto": 0, "device": 0, "passes": 1}[exit_path]
         self.step = float(step)
         self.momentum = momentum
         self.lagged_output = bool(lagged_output)
@@ -317,7 +327,7 @@ class TV(ProxOperator):
     def prior_descriptor(self):
         return {"prior_kind": _capi.PRIOR_TV_ISO, "prior_sigma": self.sigma, "tv_niter": self.niter,
                 "tv_step": self.step, "tv_betas": fgp_betas(self.niter, self.momentum),
-                "tv_lagged_output": self.lagged_output, "tv_warm": self.warm, "tv_rtol": self.rtol}
+                "tv_lagged_output": self.lagged_output, "tv_warm": self.warm, "tv_rtol": self.rtol, "tv_exit_path": self.exit_path}
 
     def _problem(self):
         if self._prob is None:
@@ -400,12 +410,9 @@ class L2_ncvx_tv(ProxOperator):
         self.isotropic = isotropic
         self.niter = niter
         self.warm = warm
-        # the reference hands rtol to its inner TV(dims, 1., niter, rtol) (algs.py:169): that prox is only used by the ME-TV branch
+        # the reference hands rtol to its inner TV(dims, 1., niter, rtol) (algs.py:169): that prox is only used by the ME-TV branch, where
+        # every image leaves the inner prox in the pass upstream's loop leaves it in (lmc_problem.ncvx_rtol; rtol = 0: always niter updates)
         self.rtol = float(rtol)
-        if Op2 is None and self.rtol > 0.0:
-            warnings.warn(f"L2_ncvx_tv(rtol={self.rtol:g}): the early exit of the inner pyproximal.TV prox (algs.py:169) is not taken on the "
-                          f"GPU -- every chain runs niter = {int(niter)} dual iterations (pass rtol=0 to silence; parity with the CPU "
-                          "checker holds at rtol = 0)", RuntimeWarning, stacklevel=2)
         self.lagged_output = bool(lagged_output)
         self._prob = None
 
@@ -417,6 +424,7 @@ class L2_ncvx_tv(ProxOperator):
         kind = _capi.NCVX_ME_TV if self.Op2 is None else (_capi.NCVX_MC_TV if self.isotropic else _capi.NCVX_MC_TV_ANISO)
         return {**base, "ncvx_kind": kind,
                 "ncvx_lambda": self.lamda, "ncvx_gamma": self.gamma, "ncvx_niter": int(self.niter),
+                "ncvx_rtol": self.rtol if self.Op2 is None else 0.0,
                 "tv_lagged_output": self.lagged_output}
 
     def _problem(self):

@@ -39,6 +39,9 @@ typedef struct {
     int tv_niter;
     double tv_step;
     const double* betas;      /* [tv_niter] momentum table (lmc_oracle.fgp_betas) */
+    double tv_rtol;           /* > 0: pyproximal.TV's per-image early exit on the relative change of the primal objective (its default 1e-4, which the
+                               * reference's calls at prox_lmc_deconv.py:122 and algs.py:169 leave in force); lmc_oracle.tv_prox_fgp(rtol=...) */
+    int* tv_passes;           /* optional [n_img] output: the pass each image's prox left in (tv_niter = ran out of passes) */
 } oc_step_config;
 
 /* (Hx)[i,j] = sum_{a,b} h[a,b] x[i-a+oy, j-b+ox], zero outside (lmc_oracle.blur).  Per pixel the taps are added in (a,b)
@@ -100,15 +103,68 @@ static void primal_row(const double* x, const double* rr, const double* ss, doub
     }
 }
 
-/* prox_{gamma TV}(x) by niter FGP dual iterations (lmc_oracle.tv_prox_fgp with rtol = 0); work = 5 images */
-static void tv_prox_img(const double* x, double* out, int H, int W, double gamma, int niter, double step, const double* betas,
-                        double* work) {
+/* numpy's pairwise summation of a contiguous float64 array (numpy/_core/src/umath/loops_utils.h.src: blocks of 128, eight partial sums),
+ * so that the objective below is the number `float(np.sum(...))` gives in lmc_oracle.tv_prox_fgp -- the early-exit test compares it with rtol */
+static double np_pairwise_sum(const double* a, size_t n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (size_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        size_t i;
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    } else {
+        size_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+    }
+}
+
+/* primal objective of the iterate `sol`: 0.5 ||x - sol||^2 + gamma TV_iso(sol)  (lmc_oracle.tv_prox_fgp, rtol branch); tmp = 1 image */
+static double tv_objective_img(const double* x, const double* sol, int H, int W, double gamma, double* tmp) {
+    const size_t n = (size_t)H * W;
+    for (size_t e = 0; e < n; ++e) { const double d = x[e] - sol[e]; tmp[e] = d * d; }
+    const double sq = np_pairwise_sum(tmp, n);
+    for (int i = 0; i < H; ++i) {
+        const double* so = sol + (size_t)i * W;
+        const double* sd = sol + (size_t)(i < H - 1 ? i + 1 : i) * W;
+        double* t = tmp + (size_t)i * W;
+        for (int j = 0; j < W; ++j) {
+            const double dr = sd[j] - so[j];
+            const double dc = (j < W - 1) ? so[j + 1] - so[j] : 0.0;
+            t[j] = sqrt(dr * dr + dc * dc);
+        }
+    }
+    return 0.5 * sq + gamma * np_pairwise_sum(tmp, n);
+}
+
+/* prox_{gamma TV}(x) by niter FGP dual iterations (lmc_oracle.tv_prox_fgp); rtol > 0: with upstream's early exit -- the iterate formed at
+ * the top of a pass is returned as soon as the relative change of its objective is below rtol (never in the first pass).  Returns the pass
+ * the image left in (niter: ran out of passes).  work = 5 images (6 with rtol > 0) */
+static int tv_prox_img(const double* x, double* out, int H, int W, double gamma, int niter, double step, const double* betas,
+                       double rtol, double* work) {
     const size_t n = (size_t)H * W;
     double *rr = work, *ss = work + n, *p = work + 2 * n, *q = work + 3 * n, *sol = work + 4 * n;
     memset(work, 0, 4 * n * sizeof(double));
     const double c = step / gamma;
+    double prev_obj = 0.0;
     for (int k = 0; k < niter; ++k) {
         for (int i = 0; i < H; ++i) primal_row(x, rr, ss, sol, H, W, i, gamma);
+        if (rtol > 0.0) {
+            const double obj = tv_objective_img(x, sol, H, W, gamma, work + 5 * n);
+            const double rel = (k > 0 && obj > 0.0) ? fabs(obj - prev_obj) / obj : 2.0 * rtol;
+            prev_obj = obj;
+            if (rel < rtol) {
+                memcpy(out, sol, n * sizeof(double));
+                return k;
+            }
+        }
         const double beta = betas[k];
         for (int i = 0; i < H; ++i) {
             const double* so = sol + (size_t)i * W;
@@ -129,9 +185,10 @@ static void tv_prox_img(const double* x, double* out, int H, int W, double gamma
         }
     }
     for (int i = 0; i < H; ++i) primal_row(x, rr, ss, out, H, W, i, gamma);
+    return niter;
 }
 
-static void step_img(const oc_step_config* c, const double* x, const double* xi, double* out, double* work) {
+static void step_img(const oc_step_config* c, const double* x, const double* xi, double* out, double* work, int* passes) {
     const int H = c->H, W = c->W;
     const size_t n = (size_t)H * W;
     double *g = work, *tmp = work + n, *px = work + 2 * n, *tvw = work + 3 * n;
@@ -164,9 +221,10 @@ static void step_img(const oc_step_config* c, const double* x, const double* xi,
                 px[e] = sg * (m > 0.0 ? m : 0.0);
             }
         } break;
-        case OC_PRIOR_TV:
-            tv_prox_img(x, px, H, W, c->t * c->prior_sigma, c->tv_niter, c->tv_step, c->betas, tvw);
-            break;
+        case OC_PRIOR_TV: {
+            const int left = tv_prox_img(x, px, H, W, c->t * c->prior_sigma, c->tv_niter, c->tv_step, c->betas, c->tv_rtol, tvw);
+            if (passes) *passes = left;
+        } break;
         default:
             memcpy(px, x, n * sizeof(double));
     }
@@ -193,7 +251,7 @@ int lmc_oc_myula_step(const oc_step_config* c, const double* x, const double* xi
     int fail = 0;
 #pragma omp parallel num_threads(n_threads)
     {
-        double* work = (double*)malloc(8 * n * sizeof(double));
+        double* work = (double*)malloc(9 * n * sizeof(double));
         if (!work) {
 #pragma omp atomic write
             fail = 1;
@@ -201,22 +259,24 @@ int lmc_oc_myula_step(const oc_step_config* c, const double* x, const double* xi
 #pragma omp barrier
         if (!fail) {
 #pragma omp for schedule(dynamic, 1)
-            for (int im = 0; im < n_img; ++im) step_img(c, x + (size_t)im * n, xi + (size_t)im * n, out + (size_t)im * n, work);
+            for (int im = 0; im < n_img; ++im)
+                step_img(c, x + (size_t)im * n, xi + (size_t)im * n, out + (size_t)im * n, work, c->tv_passes ? c->tv_passes + im : NULL);
         }
         free(work);
     }
     return fail ? -2 : 0;
 }
 
+/* rtol > 0: with the early exit; passes (optional, [n_img]): the pass each image left in */
 int lmc_oc_tv_prox(const double* x, double* out, int n_img, int H, int W, double gamma, int niter, double step, const double* betas,
-                   int n_threads) {
+                   double rtol, int* passes, int n_threads) {
     if (!x || !out || H <= 0 || W <= 0 || niter < 0 || (niter > 0 && !betas)) return -1;
     const size_t n = (size_t)H * W;
     if (n_threads < 1) n_threads = 1;
     int fail = 0;
 #pragma omp parallel num_threads(n_threads)
     {
-        double* work = (double*)malloc(5 * n * sizeof(double));
+        double* work = (double*)malloc(6 * n * sizeof(double));
         if (!work) {
 #pragma omp atomic write
             fail = 1;
@@ -224,7 +284,10 @@ int lmc_oc_tv_prox(const double* x, double* out, int n_img, int H, int W, double
 #pragma omp barrier
         if (!fail) {
 #pragma omp for schedule(dynamic, 1)
-            for (int im = 0; im < n_img; ++im) tv_prox_img(x + (size_t)im * n, out + (size_t)im * n, H, W, gamma, niter, step, betas, work);
+            for (int im = 0; im < n_img; ++im) {
+                const int left = tv_prox_img(x + (size_t)im * n, out + (size_t)im * n, H, W, gamma, niter, step, betas, rtol, work);
+                if (passes) passes[im] = left;
+            }
         }
         free(work);
     }

@@ -24,7 +24,8 @@ class _Cfg(C.Structure):
                 ("kh", C.c_int), ("kw", C.c_int), ("oy", C.c_int), ("ox", C.c_int),
                 ("sigma_f", C.c_double), ("tau", C.c_double), ("gamma", C.c_double),
                 ("prior_kind", C.c_int), ("prior_sigma", C.c_double), ("t", C.c_double),
-                ("tv_niter", C.c_int), ("tv_step", C.c_double), ("betas", _dp)]
+                ("tv_niter", C.c_int), ("tv_step", C.c_double), ("betas", _dp),
+                ("tv_rtol", C.c_double), ("tv_passes", C.POINTER(C.c_int))]
 
 
 _lib = None
@@ -42,7 +43,8 @@ def lib():
         _lib = C.CDLL(_SO)
         _lib.lmc_oc_max_threads.restype = C.c_int
         _lib.lmc_oc_myula_step.argtypes = [C.POINTER(_Cfg), _dp, _dp, _dp, C.c_int, C.c_int]
-        _lib.lmc_oc_tv_prox.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, _dp, C.c_int]
+        _lib.lmc_oc_tv_prox.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, _dp, C.c_double,
+                                        C.POINTER(C.c_int), C.c_int]
         _lib.lmc_oc_blur.argtypes = [_dp, _dp, C.c_int] + [C.c_int] * 2 + [_dp] + [C.c_int] * 5
     return _lib
 
@@ -59,8 +61,10 @@ def max_threads():
     return int(lib().lmc_oc_max_threads())
 
 
-def myula_step(x, y, h, offset, sigma_f, tau, gamma, prior, xi, mask=None, threads=1):
-    """Same arguments and meaning as ``lmc_oracle.myula_step`` (priors none / l2 / l1 / tv), float64."""
+def myula_step(x, y, h, offset, sigma_f, tau, gamma, prior, xi, mask=None, threads=1, passes=None):
+    """Same arguments and meaning as ``lmc_oracle.myula_step`` (priors none / l2 / l1 / tv), float64.  ``prior["rtol"] > 0``: the TV prox
+    with upstream's early exit (``lmc_oracle.tv_prox_fgp(rtol=...)``, image by image); ``passes``: optional int32 array [n_img] that
+    receives the pass each image's prox left in."""
     from . import lmc_oracle as O
     x = _f64(x)
     xi = _f64(xi)
@@ -95,6 +99,10 @@ def myula_step(x, y, h, offset, sigma_f, tau, gamma, prior, xi, mask=None, threa
         b = _f64(O.fgp_betas(K, prior.get("momentum", "unlocbox")) if b is None else b)
         keep.append(b)
         cfg.tv_niter, cfg.tv_step, cfg.betas = K, float(prior.get("step", 0.125)), _p(b)
+        cfg.tv_rtol = float(prior.get("rtol", 0.0))
+        if passes is not None:
+            assert passes.dtype == np.int32 and passes.size == n_img and passes.flags.c_contiguous
+            cfg.tv_passes = passes.ctypes.data_as(C.POINTER(C.c_int))
     out = np.empty_like(x)
     rc = lib().lmc_oc_myula_step(C.byref(cfg), _p(x), _p(xi), _p(out), n_img, int(threads))
     if rc != 0:
@@ -102,16 +110,19 @@ def myula_step(x, y, h, offset, sigma_f, tau, gamma, prior, xi, mask=None, threa
     return out
 
 
-def tv_prox_fgp(x, gamma, niter, step=0.125, betas=None, momentum="unlocbox", threads=1):
+def tv_prox_fgp(x, gamma, niter, step=0.125, betas=None, momentum="unlocbox", threads=1, rtol=0.0, return_passes=False):
     from . import lmc_oracle as O
     x = _f64(x)
     Hh, W = x.shape[-2:]
+    n_img = x.size // (Hh * W)
     b = _f64(O.fgp_betas(niter, momentum) if betas is None else betas)
     out = np.empty_like(x)
-    rc = lib().lmc_oc_tv_prox(_p(x), _p(out), x.size // (Hh * W), Hh, W, float(gamma), int(niter), float(step), _p(b), int(threads))
+    passes = np.zeros(n_img, dtype=np.int32)
+    rc = lib().lmc_oc_tv_prox(_p(x), _p(out), n_img, Hh, W, float(gamma), int(niter), float(step), _p(b), float(rtol),
+                              passes.ctypes.data_as(C.POINTER(C.c_int)), int(threads))
     if rc != 0:
         raise RuntimeError(f"lmc_oc_tv_prox failed ({rc})")
-    return out
+    return (out, passes) if return_passes else out
 
 
 def blur(x, h, offset, adjoint=False):

@@ -126,7 +126,7 @@ def test_pipe_kernel_with_me_tv_term_matches_tile(la):
     for v in ("tile", "auto"):
         la.set_step_variant(v)
         pf = la.L2_ncvx_tv(dims=shape, Op=la.Convolve2D(shape, h, offset=off), b=y.ravel(), sigma=1 / 0.75 ** 2, lamda=0.3, gamma=15.0,
-                           isotropic=True, niter=10)
+                           isotropic=True, niter=10, rtol=0.0)
         smp = la.MYULASampler(pf, la.TV(shape, sigma=0.3, niter=10), shape, n_chains=2, tau=0.1125, gamma=0.5625, seed=1)
         smp.set_state(img)
         smp.step(3)
@@ -173,7 +173,7 @@ def test_pipe_me_tv_inner_prox_chained(la):
     for v in ("tile", "auto"):
         la.set_step_variant(v)
         pf = la.L2_ncvx_tv(dims=shape, Op=la.Convolve2D(shape, h, offset=off), b=y.ravel(), sigma=1 / 0.75 ** 2, lamda=0.3, gamma=15.0,
-                           isotropic=True, niter=20)
+                           isotropic=True, niter=20, rtol=0.0)
         outs[("g", v)] = pf.grad((img + 3.0).ravel())
         smp = la.MYULASampler(pf, la.TV(shape, sigma=0.3, niter=10), shape, n_chains=2, tau=0.1125, gamma=0.5625, seed=1)
         smp.set_state(img)

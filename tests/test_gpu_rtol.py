@@ -1,0 +1,194 @@
+"""pyproximal.TV's per-image early exit (rtol = 1e-4: upstream's default at prox_lmc_deconv.py:122, the class's own at algs.py:130,169) decided
+ON THE DEVICE (ABI 3): per-chain live stage counts in the fused pipeline, primal objectives as by-products, predict / verify / re-run.
+
+Checked against: the CPU checker's rtol branch chain by chain (iterates AND the pass every chain leaves in), the committed outputs of the
+reference's own loops at its configured rtol (tests/golden/algs_rtol.npz: MYULA with the TV prior, the ME-TV gradient, MYULA with the ME-TV
+term), and the pass-by-pass device path of ABI 2."""
+import numpy as np
+import pytest
+
+from oracle import lmc_oracle as O
+from oracle import lmc_oracle_c as OC
+
+pytestmark = pytest.mark.gpu
+
+SIGMA = 0.75
+GAMMA, TAU = SIGMA ** 2, 0.2 * SIGMA ** 2
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+    assert torch.cuda.is_available()
+    import lmc_atomi_amd as la
+    return la
+
+
+def images(shape, n, seed):
+    """n images that leave a 10-pass prox in different passes: flat / piecewise constant / textured at several noise levels"""
+    rng = np.random.default_rng(seed)
+    base = np.zeros(shape)
+    base[shape[0] // 5:shape[0] // 2, shape[1] // 6:2 * shape[1] // 3] = 160.0
+    base[shape[0] // 2:, shape[1] // 2:] = 70.0
+    base += np.linspace(0, 25, shape[1])[None, :]
+    out = np.empty((n,) + shape)
+    for c in range(n):
+        out[c] = base * (0.2 + 0.4 * (c % 4)) + rng.normal(0, [0.05, 0.6, 3.0, 12.0, 40.0][c % 5], shape)
+    out[0] = 0.0            # x0 = 0 (prox_lmc_deconv.py:135): every objective is zero, the prox runs out of passes
+    return out
+
+
+@pytest.mark.parametrize("shape,K,gam", [((24, 136), 10, 0.17), ((40, 264), 10, 0.17), ((36, 512), 10, 0.17), ((30, 200), 7, 0.17), ((28, 256), 10, 2.0),
+                                         ((33, 384), 3, 0.17), ((25, 136), 1, 0.17)])
+def test_prox_and_exit_pass_equal_the_checkers_chain_by_chain(la, shape, K, gam):
+    """prox alone (no data term, no noise): out = (1 - tau/gamma) x + (tau/gamma) prox(x), twice in a row -- the second call starts from
+    the first call's pass counts as predictions (all right: same inputs), the first from none (every chain runs all passes first)."""
+    n = 10
+    x = images(shape, n, K)
+    pg = la.TV(shape, sigma=gam / GAMMA, niter=K, rtol=1e-4)
+    smp = la.MYULASampler(None, pg, shape, n_chains=n, tau=TAU, gamma=GAMMA, noise="none")
+    assert smp.kernel_name.startswith("(no step")
+    ref, passes = OC.tv_prox_fgp(x, gam, K, rtol=1e-4, return_passes=True)
+    want = (1 - TAU / GAMMA) * x + (TAU / GAMMA) * ref
+    for call in range(2):
+        smp.set_state(x)
+        smp.step(1)
+        assert "per-chain exit" in smp.kernel_name
+        got = smp.get_state().cpu().numpy()
+        ps, reruns = smp.tv_exit_stats("prior")
+        np.testing.assert_array_equal(ps.cpu().numpy(), passes)
+        for c in range(n):
+            assert rel(got[c], want[c]) < 2e-6, (call, c, rel(got[c], want[c]))
+        assert reruns[2] == 0
+        if call == 0:
+            first = list(reruns)
+            assert first[0] == int(np.sum(passes < K)) and first[1] == 0      # the chains that left early ran again with their count, once
+        else:
+            assert list(reruns) == first                                      # nothing to repeat: every prediction held
+    assert len(set(passes.tolist())) >= (3 if K >= 7 else 1), passes
+    smp.close()
+    # the stateless prox (lmc_fused_eval) takes the same path
+    px = pg.prox(x[3].ravel(), GAMMA).reshape(shape)
+    assert rel(px, ref[3]) < 2e-6
+
+
+@pytest.mark.parametrize("shape,k", [((24, 136), 5), ((40, 264), 7), ((30, 512), 6)])
+def test_fused_step_with_the_exit_follows_the_checker_over_iterations(la, shape, k):
+    """The whole MYULA update with the exit inside the fused launch (blur gradient, injected noise), 8 iterations: states against the checker's
+    rtol branch; the pass-by-pass path (exit_path='passes') gives the same states and the same pass counts."""
+    rng = np.random.default_rng(k)
+    img = images(shape, 2, 1)[1]
+    h = np.ones((k, k)) / (k * k)
+    y = O.blur(img, h, (k // 2, k // 2)) + rng.normal(0, SIGMA, shape)
+    C_, nit = 5, 8
+    x0 = img[None] + rng.normal(0, 8, (C_,) + shape)
+    x0[0] = 0.0
+    noise = rng.standard_normal((nit, C_) + shape)
+    pf = la.L2(Op=la.Convolve2D(shape, h, offset=(k // 2, k // 2)), b=y, sigma=1 / SIGMA ** 2)
+    outs = {}
+    for path in ("device", "passes"):
+        smp = la.MYULASampler(pf, la.TV(shape, sigma=0.3, niter=10, rtol=1e-4, exit_path=path), shape, n_chains=C_, tau=TAU, gamma=GAMMA, noise="injected")
+        smp.set_state(x0)
+        smp.step(nit, noise=noise)
+        outs[path] = smp.get_state().cpu().numpy()
+        if path == "device":
+            assert "per-chain exit" in smp.kernel_name
+            ps, reruns = smp.tv_exit_stats()
+            assert reruns[2] == 0
+        else:
+            assert "per-chain exit" not in smp.kernel_name
+        smp.close()
+    pri = {"kind": "tv", "sigma": 0.3, "niter": 10, "t": GAMMA, "rtol": 1e-4}
+    x = x0.copy()
+    last = np.zeros(C_, dtype=np.int32)
+    for i in range(nit):
+        x = OC.myula_step(x, y, h, (k // 2, k // 2), 1 / SIGMA ** 2, TAU, GAMMA, pri, noise[i], passes=last)
+    assert rel(outs["device"], x) < 3e-5, rel(outs["device"], x)
+    assert rel(outs["device"], outs["passes"]) < 3e-6, rel(outs["device"], outs["passes"])
+    np.testing.assert_array_equal(ps.cpu().numpy(), last)            # the passes of the last iteration
+
+
+def test_predictions_hold_from_one_iteration_to_the_next(la):
+    """Philox chains from x0 = 0: after the transient almost every chain leaves its prox in the pass it left in one iteration earlier, so
+    the second and third rounds are (nearly) empty -- the statistic the speed of this path rests on."""
+    shape, C_ = (64, 264), 48
+    rng = np.random.default_rng(2)
+    img = images(shape, 2, 3)[1]
+    h = np.ones((5, 5)) / 25.0
+    y = O.blur(img, h, (2, 2)) + rng.normal(0, SIGMA, shape)
+    pf = la.L2(Op=la.Convolve2D(shape, h, offset=(2, 2)), b=y, sigma=1 / SIGMA ** 2)
+    smp = la.MYULASampler(pf, la.TV(shape, sigma=0.3, niter=10, rtol=1e-4), shape, n_chains=C_, tau=TAU, gamma=GAMMA, seed=5)
+    smp.step(30)
+    _, r0 = smp.tv_exit_stats()
+    smp.step(30)
+    ps, r1 = smp.tv_exit_stats()
+    late = r1[0] - r0[0]
+    assert r1[2] == 0
+    assert late <= 0.15 * 30 * C_, (r0, r1)               # at most 15 % of the chain-iterations were mispredicted once the chains have left x0
+    assert 1 <= int(ps.min()) and int(ps.max()) <= 10
+    smp.close()
+
+
+def test_drop_in_reproduces_the_reference_loops_at_their_configured_rtol(la, golden):
+    """tests/golden/algs_rtol.npz -- outputs of the reference's OWN code (algs.MoreauYosidaUnadjustedLangevin, algs.L2_ncvx_tv) with the TV
+    proxes keeping rtol = 1e-4: the TV-prior trajectory, the ME-TV gradient (inner prox: 50 passes at most, algs.py:169), and the MYULA
+    trajectory with the ME-TV term.  The same objects at rtol = 0 reproduce the rtol = 0 fixtures, and the two sets differ."""
+    g = golden("algs_rtol.npz")
+    ny, nx, k, seed = (int(v) for v in g["meta"])
+    sigma, tau_reg, tau, gamma = (float(v) for v in g["params"])
+    shape = (ny, nx)
+    H = la.Convolve2D(shape, g["h"], offset=(k // 2, k // 2))
+    for tag, rtol in (("rtol1e-4", 1e-4), ("rtol0", 0.0)):
+        pf = la.L2(Op=H, b=g["y"], sigma=1 / sigma ** 2)
+        xs = la.MoreauYosidaUnadjustedLangevin(pf, la.TV(shape, sigma=tau_reg, niter=10, rtol=rtol), np.zeros(ny * nx), tau=tau, gamma=gamma,
+                                               niter=41, seed=seed, rng="pcg64")
+        assert rel(xs[::10], g[f"myula_tv_{tag}"][:5]) < 5e-5, (tag, rel(xs[::10], g[f"myula_tv_{tag}"][:5]))
+        # the inner prox of the reference class keeps ITS rtol = 1e-4 in both sets (make_golden.py: me = L2_ncvx_tv(..., rtol=1e-4)); what the
+        # tag switches is whether the stand-in for pyproximal.TV honours it
+        me = la.L2_ncvx_tv(dims=shape, Op=H, b=g["y"].ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=15.0, isotropic=True, niter=50, rtol=rtol, warm=True)
+        got, ref = me.grad(g["ncvx_x"].copy()), g[f"ncvx_me_grad_{tag}"]
+        assert rel(got, ref) < 1e-4, (tag, rel(got, ref))
+        xs = la.MoreauYosidaUnadjustedLangevin(me, la.TV(shape, sigma=tau_reg, niter=10, rtol=rtol), np.zeros(ny * nx), tau=tau, gamma=gamma,
+                                               niter=20, seed=seed, rng="pcg64")
+        assert rel(xs[::5], g[f"myula_me_tv_{tag}"]) < 1e-4, (tag, rel(xs[::5], g[f"myula_me_tv_{tag}"]))
+    assert rel(g["ncvx_me_grad_rtol1e-4"], g["ncvx_me_grad_rtol0"]) > 1e-3          # the exit is visible in the fixtures (1.3e-2)
+
+
+@pytest.mark.parametrize("shape,niter", [((24, 136), 50), ((40, 264), 50), ((20, 512), 30), ((24, 136), 14), ((22, 96), 20)])
+def test_me_tv_inner_prox_leaves_where_the_checkers_does(la, shape, niter):
+    """The chained inner prox of the ME-TV term (up to 60 passes as links of 10): every image leaves in the link that holds its last pass --
+    against the checker's rtol branch through the gradient of the term (which is what the sampler uses), and the pass counts through a sampler.
+    (22 x 96: narrower than the pipeline covers -- the pass-by-pass fallback.)"""
+    n = 6
+    x = images(shape, n, niter)[:n] + 40.0
+    rng = np.random.default_rng(niter)
+    h = np.ones((5, 5)) / 25.0
+    y = O.blur(x[1], h, (2, 2)) + rng.normal(0, SIGMA, shape)
+    lam, gam = 0.3, 15.0
+    me = la.L2_ncvx_tv(dims=shape, Op=la.Convolve2D(shape, h, offset=(2, 2)), b=y.ravel(), sigma=1 / SIGMA ** 2, lamda=lam, gamma=gam, isotropic=True,
+                       niter=niter, rtol=1e-4)
+    got = me.grad(x.reshape(n, -1)).reshape((n,) + shape)
+    prox, passes = OC.tv_prox_fgp(x, gam, niter, rtol=1e-4, return_passes=True)
+    fixed = OC.tv_prox_fgp(x, gam, niter)
+    for c in range(n):
+        gl2 = (1 / SIGMA ** 2) * O.blur_adjoint(O.blur(x[c], h, (2, 2)) - y, h, (2, 2))
+        want = gl2 - lam * (x[c] - prox[c]) / gam
+        want_fixed = gl2 - lam * (x[c] - fixed[c]) / gam
+        assert rel(got[c], want) < 2e-5, (c, passes[c], rel(got[c], want))
+        if passes[c] < niter - 5:
+            assert rel(got[c], want_fixed) > 5 * rel(got[c], want), (c, passes[c])
+    assert len(set(passes.tolist())) >= 2, passes
+    if shape[1] > 128:
+        smp = la.MYULASampler(me, None, shape, n_chains=n, tau=TAU, gamma=GAMMA, noise="none")
+        smp.set_state(x)
+        smp.step(1)
+        ps, reruns = smp.tv_exit_stats("ncvx")
+        np.testing.assert_array_equal(ps.cpu().numpy(), passes)
+        assert reruns[2] == 0
+        smp.close()

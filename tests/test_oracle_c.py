@@ -80,3 +80,33 @@ def test_rejects_bad_arguments():
         rc = OC.lib().lmc_oc_myula_step(OC.C.byref(cfg), OC._p(x), OC._p(x), OC._p(x.copy()), 1, 1)
         if rc != 0:
             raise RuntimeError(rc)
+
+
+def test_tv_early_exit_is_bit_identical_and_leaves_in_the_same_pass():
+    """The rtol branch (pyproximal.TV's per-image early exit, in force at prox_lmc_deconv.py:122 and algs.py:169): the C twin forms the objective
+    with numpy's pairwise summation, so it leaves in the very pass lmc_oracle.tv_prox_fgp leaves in and returns the same bits."""
+    rng = np.random.default_rng(0)
+    seen = set()
+    for trial in range(8):
+        Hh, W = [(24, 136), (33, 47), (64, 64), (17, 200)][trial % 4]
+        img = np.zeros((Hh, W))
+        img[5:15, 10:30] = 100 + 50 * rng.random()
+        img += rng.normal(0, [0.5, 3, 10][trial % 3], (Hh, W))
+        for rtol in (1e-4, 1e-3, 1e-2):
+            a = O.tv_prox_fgp(img, 0.17, 10, rtol=rtol)
+            b, ps = OC.tv_prox_fgp(img, 0.17, 10, rtol=rtol, return_passes=True)
+            assert np.array_equal(a, b), (trial, rtol)
+            seen.add(int(ps[0]))
+            # the pass it left in: the iterate after that many dual updates
+            assert np.array_equal(a, O.tv_prox_fgp(img, 0.17, int(ps[0]))), (trial, rtol, ps)
+    assert len(seen) >= 3, seen
+    # inside the MYULA step, with the pass counts reported per chain
+    y = _img(rng, 24, 40)
+    x = np.stack([np.zeros((24, 40)), y + rng.normal(0, 3, y.shape), y + rng.normal(0, 30, y.shape)])
+    xi = rng.standard_normal(x.shape)
+    prior = {"kind": "tv", "sigma": 0.3, "niter": 10, "t": 0.5625, "rtol": 1e-4}
+    ps = np.zeros(3, dtype=np.int32)
+    got = OC.myula_step(x, y, np.ones((5, 5)) / 25, (2, 2), 1 / 0.5625, 0.1125, 0.5625, prior, xi, threads=2, passes=ps)
+    want = O.myula_step(x, y, np.ones((5, 5)) / 25, (2, 2), 1 / 0.5625, 0.1125, 0.5625, prior, xi)
+    assert np.array_equal(got, want)
+    assert ps[0] == 10 and 1 <= ps[1] <= 10
