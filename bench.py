@@ -354,14 +354,14 @@ def main():
             try:
                 ps, rr = smp.tv_exit_stats("prior")
                 pc = np.bincount(ps.cpu().numpy(), minlength=args.tv_iters + 1)
-                out["config"]["tv_exit"] = {"passes_histogram_last_iteration": pc.tolist(), "reruns_after_round_1_2_3": rr,
+                out["config"]["tv_exit"] = {"passes_histogram_last_iteration": pc.tolist(), "reruns_after_round_1_2_3_4": rr,
                                             "chain_iterations": int(C * (args.warmup + args.steps * len(regions)))}
             except Exception as exc:
                 out["config"]["tv_exit"] = f"pass-by-pass path ({exc})"
         if args.ncvx_rtol and args.ncvx == "me" and args.alg == "myula":
             ps, rr = smp.tv_exit_stats("ncvx")
             pc = np.bincount(ps.cpu().numpy(), minlength=(args.ncvx_iters or args.tv_iters) + 1)
-            out["config"]["ncvx_exit"] = {"passes_histogram_last_iteration": pc.tolist(), "reruns_after_round_1_2_3": rr}
+            out["config"]["ncvx_exit"] = {"passes_histogram_last_iteration": pc.tolist(), "reruns_after_round_1_2_3_4": rr}
         if args.alg == "mymala":
             out["config"]["acceptance_rate_mean"] = float(smp.acceptance_rate().mean())
             out["config"]["tau_scale"] = args.tau_scale

@@ -118,7 +118,7 @@ typedef struct lmc_problem {
    *    W % 4 == 0 up to 256 columns and W % 8 == 0 above, tv_niter <= 60): the fused launch runs every chain with a PREDICTED pass count
    *    (the pass it left in at the previous call), the stages past it hand the dual through, and the primal objectives of all the iterates
    *    formed are by-products; a one-thread-per-chain kernel replays the exit test on them and the chains whose prediction was wrong
-   *    run again (at most two more rounds settle every chain; the launches of settled chains return at once).
+   *    run again (at most three more rounds settle every chain; the launches of settled chains return at once).
    *  - pass by pass (ABI 2; everything else): one launch per loop pass for the iterate, one for its objective; the host reads the number
    *    of images still iterating after every pass, so this path SYNCHRONISES the stream.
    * Not with tv_warm or MYMALA. */
@@ -302,8 +302,8 @@ int lmc_sampler_last_step_timing(lmc_sampler* s, float* total_ms, int32_t* n_lau
 const char* lmc_sampler_kernel_name(const lmc_sampler* s);
 /* Early-exit statistics of the latest TV prox evaluated with tv_rtol > 0 (which = 0) or of the ME-TV inner prox with ncvx_rtol > 0 (which = 1)
  * on the device path: passes_dev [n_chains] int32 (device, nullable) = the loop pass each chain left in (tv_niter: it ran out of passes);
- * reruns_host[3] (host, nullable) = chains whose run had to be repeated after round 1 / 2 / 3 of the latest call, summed over all calls since
- * creation (round 3's count stays 0 by construction).  Synchronises `stream`.  LMC_E_STATE when the sampler does not use the device path. */
+ * reruns_host[4] (host, nullable) = chains whose run had to be repeated after round 1 / 2 / 3 / 4, summed over all calls since creation
+ * (round 4's count stays 0 by construction).  Synchronises `stream`.  LMC_E_STATE when the sampler does not use the device path. */
 int lmc_sampler_tv_exit_stats(lmc_sampler* s, int32_t which, int32_t* passes_dev, uint64_t* reruns_host, void* stream);
 
 /* ---- multi-GPU: the one collective of the path ----------------------------------------------

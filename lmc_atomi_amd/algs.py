@@ -159,9 +159,9 @@ class MYULASampler:
     def tv_exit_stats(self, which="prior"):
         """Early-exit statistics of the device path (``TV(rtol > 0)`` / ``L2_ncvx_tv(rtol > 0)``): ``(passes, reruns)`` -- the loop pass each
         chain's latest prox left in (int32 tensor, ``niter`` = it ran out of passes) and the number of chain runs that had to be repeated
-        after rounds 1 / 2 / 3 since the sampler was created (``which``: 'prior' = the TV prior's prox, 'ncvx' = the ME-TV inner prox)."""
+        after rounds 1 / 2 / 3 / 4 since the sampler was created (``which``: 'prior' = the TV prior's prox, 'ncvx' = the ME-TV inner prox)."""
         passes = torch.empty(self.n_chains, dtype=torch.int32, device=self.device)
-        rr = (C.c_uint64 * 3)()
+        rr = (C.c_uint64 * 4)()
         _capi.check(_dev.lib().lmc_sampler_tv_exit_stats(self._h, {"prior": 0, "ncvx": 1}[which], _dev.ptr(passes), rr, _dev.stream_ptr(self.device)))
         return passes, [int(v) for v in rr]
 

@@ -86,29 +86,32 @@ struct Problem {
 // in at the previous call (pred: the prediction of the next one), the primal objectives of the iterates [n][stride], and three counters of re-runs.
 struct RtState {
   int* kc = nullptr;
+  int* start = nullptr;
   int* pred = nullptr;
   double* obj = nullptr;
-  unsigned long long* reruns = nullptr;
+  unsigned long long* reruns = nullptr;     // [4]: chains that had to run again after rounds 1 .. 4 (the last stays 0 by construction)
   int stride = 0;
   size_t n = 0;
   hipError_t need(size_t n_img, int niter) {
     if (n_img <= n && niter + 1 <= stride) return hipSuccess;
     release();
     hipError_t e = hipMalloc(&kc, sizeof(int) * n_img);
+    if (e == hipSuccess) e = hipMalloc(&start, sizeof(int) * n_img);
     if (e == hipSuccess) e = hipMalloc(&pred, sizeof(int) * n_img);
     if (e == hipSuccess) e = hipMalloc(&obj, sizeof(double) * n_img * (size_t)(niter + 1));
-    if (e == hipSuccess) e = hipMalloc(&reruns, sizeof(unsigned long long) * 3);
+    if (e == hipSuccess) e = hipMalloc(&reruns, sizeof(unsigned long long) * 4);
     if (e == hipSuccess) e = hipMemset(pred, 0, sizeof(int) * n_img);           // 0 = no prediction yet: the first call runs every pass
-    if (e == hipSuccess) e = hipMemset(reruns, 0, sizeof(unsigned long long) * 3);
+    if (e == hipSuccess) e = hipMemset(reruns, 0, sizeof(unsigned long long) * 4);
     if (e == hipSuccess) { n = n_img; stride = niter + 1; }
     return e;
   }
   void release() {
     if (kc) (void)hipFree(kc);
+    if (start) (void)hipFree(start);
     if (pred) (void)hipFree(pred);
     if (obj) (void)hipFree(obj);
     if (reruns) (void)hipFree(reruns);
-    kc = pred = nullptr; obj = nullptr; reruns = nullptr; n = 0; stride = 0;
+    kc = start = pred = nullptr; obj = nullptr; reruns = nullptr; n = 0; stride = 0;
   }
 };
 
@@ -611,19 +614,21 @@ bool needs_tv_state(const Problem& q) {
 // The TV prox inside A (a complete StepArgs: prox only, or the whole fused update when A.tv.niter <= 10) with upstream's per-image early exit,
 // decided on the device: every chain runs with the pass count it left in last time (rt.pred), the launch leaves the primal objectives of
 // the iterates behind, tv_rt_decide replays upstream's test on them, and the chains whose prediction was wrong run again -- with the exact
-// count when the objectives already show it, else with all passes (whose objectives show it) and then once more.  Three rounds settle
-// every chain; the workgroups of settled chains return at once, so rounds two and three cost a few microseconds when the predictions hold.
-// No host synchronisation.  (lmc_ops.hip: tv_rt_begin / tv_rt_decide; lmc_step_pipe_rt.hip.)
+// count when the objectives already show it, else with one pass more, then with all passes (whose objectives show it) and then once more.
+// Four rounds settle every chain; the workgroups of settled chains return at once, so the later rounds cost a few microseconds when the
+// predictions hold, and a chained prox re-runs from the link the change lies in, not from its first.  No host synchronisation.
+// (lmc_ops.hip: tv_rt_begin / tv_rt_decide; lmc_step_pipe_rt.hip.)
+constexpr int kRtRounds = 4;
 int tv_prox_rt(lmc::StepArgs A, RtState& rt, float rtol, float* st0, float* st1, hipStream_t st) {
   const int niter = A.tv.niter;
   if (!rt.kc || rt.n < (size_t)A.C || rt.stride < niter + 1) return fail(LMC_E_STATE, "early-exit buffers are missing");
-  A.rt_kc = rt.kc; A.rt_obj = rt.obj; A.rt_stride = rt.stride;
-  HIP_TRY(lmc::launch_tv_rt_begin(A.C, rt.pred, rt.kc, rt.obj, rt.stride, niter, st));
-  for (int round = 0; round < 3; ++round) {
+  A.rt_kc = rt.kc; A.rt_start = rt.start; A.rt_obj = rt.obj; A.rt_stride = rt.stride;
+  HIP_TRY(lmc::launch_tv_rt_begin(A.C, rt.pred, rt.kc, rt.start, rt.obj, rt.stride, niter, st));
+  for (int round = 0; round < kRtRounds; ++round) {
     hipError_t e = lmc::launch_step_pipe_rt(A, st, st0, st1);
     if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "the device-side early exit of the TV prox does not cover this configuration");
     HIP_TRY(e);
-    HIP_TRY(lmc::launch_tv_rt_decide(A.C, rt.kc, rt.pred, rt.obj, rt.stride, niter, (double)rtol, rt.reruns + round, st));
+    HIP_TRY(lmc::launch_tv_rt_decide(A.C, rt.kc, rt.start, rt.pred, rt.obj, rt.stride, niter, (double)rtol, round, rt.reruns + round, st));
   }
   return LMC_OK;
 }
@@ -1920,10 +1925,10 @@ int lmc_sampler_tv_exit_stats(lmc_sampler* s, int32_t which, int32_t* passes_dev
   if (!rt.kc) return fail(LMC_E_STATE, "this sampler does not run the device-side early exit for that prox (tv_rtol / ncvx_rtol = 0, or the pass-by-pass path)");
   hipStream_t st = S(stream);
   if (passes_dev) HIP_TRY(hipMemcpyAsync(passes_dev, rt.pred, sizeof(int) * (size_t)s->C, hipMemcpyDeviceToDevice, st));
-  unsigned long long r[3] = {0, 0, 0};
+  unsigned long long r[4] = {0, 0, 0, 0};
   if (reruns_host) HIP_TRY(hipMemcpyAsync(r, rt.reruns, sizeof r, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  if (reruns_host) for (int i = 0; i < 3; ++i) reruns_host[i] = r[i];
+  if (reruns_host) for (int i = 0; i < 4; ++i) reruns_host[i] = r[i];
   return LMC_OK;
 }
 

@@ -80,10 +80,11 @@ struct StepArgs {
   // pipe kernel, RT instantiations only: per-chain early exit of the TV prox (pyproximal.TV's rtol; lmc_problem.tv_rtol / ncvx_rtol).  A chain's
   // workgroup runs rt_kc[c] dual updates in all (counted over the links of a chained prox; this launch holds updates rt_base + 1 .. rt_base + K),
   // the later stages pass the dual through; it returns at once when rt_kc[c] <= rt_base (the chain left in an earlier link, or needs no run:
-  // rt_kc[c] < 0).  By-products: the primal objective 0.5 ||x - sol_j||^2 + gamma TV(sol_j) of every iterate formed -- stage g adds that of
+  // rt_kc[c] < 0), or when this link lies before rt_start[c] (its result of an earlier round is still valid).  By-products: the primal objective 0.5 ||x - sol_j||^2 + gamma TV(sol_j) of every iterate formed -- stage g adds that of
   // its input iterate to rt_obj[c][g - 1], the combine wave that of the iterate it returns to rt_obj[c][rt_kc[c]] (unless that is rt_total,
   // the iterate returned untested).  fp64 sums; rt_obj must be zero where this launch adds.
   const int* rt_kc;
+  const int* rt_start;     // [C] (chained prox) first link chain c needs in this round: the links before it return at once -- their work of an earlier round stands
   double* rt_obj;
   int rt_stride, rt_base, rt_total;
 };

@@ -42,8 +42,9 @@ hipError_t launch_tv_objective(const float* x, const float* sol, int64_t n, int 
 hipError_t launch_tv_rtol_decide(int64_t n, double* prev, double* cur, int* flag, int pass, double rtol, int* n_active, hipStream_t st);
 hipError_t launch_tv_rtol_select(const float* tmp, float* sol, const int* flag, int pass, int64_t n, size_t img, hipStream_t st);
 // the early exit without leaving the device (speculate / verify / re-run; lmc_ops.hip, lmc_capi.hip: tv_prox_rt)
-hipError_t launch_tv_rt_begin(int64_t n, const int* pred, int* kc, double* obj, int stride, int niter, hipStream_t st);
-hipError_t launch_tv_rt_decide(int64_t n, int* kc, int* pred, double* obj, int stride, int niter, double rtol, unsigned long long* reruns, hipStream_t st);
+hipError_t launch_tv_rt_begin(int64_t n, const int* pred, int* kc, int* start, double* obj, int stride, int niter, hipStream_t st);
+hipError_t launch_tv_rt_decide(int64_t n, int* kc, int* start, int* pred, double* obj, int stride, int niter, double rtol, int round,
+                               unsigned long long* reruns, hipStream_t st);
 int hbm_copy_probe_shapes();
 hipError_t launch_hbm_copy_probe(const float* x, float* y, size_t n_floats, int shape, hipStream_t st);
 hipError_t launch_noise(float* out, int C, int H, int W, uint32_t key0, uint32_t key1, uint32_t iteration,

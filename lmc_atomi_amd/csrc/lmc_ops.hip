@@ -782,24 +782,37 @@ hipError_t launch_tv_rtol_select(const float* tmp, float* sol, const int* flag, 
 // ---- the same early exit without leaving the device (lmc_capi.hip: tv_prox_rt): speculate, verify, re-run -------------------------------------
 // A chain's prox runs with a PREDICTED number of dual updates k (the pass it left in at the previous call: the objective is a sum over the
 // whole image and moves little from one MYULA iterate to the next), fused in the RT instantiations of the pipe kernel, which leave the primal
-// objective of every iterate they form in obj[c][0 .. k].  This kernel replays upstream's test on them, one thread per chain:
+// objective of every iterate they form in obj[c][0 .. k].  tv_rt_decide replays upstream's test on them, one thread per chain:
 //   the first pass j in 1 .. min(k, niter - 1) with |obj_j - obj_{j-1}| / obj_j < rtol (obj_j > 0) is the pass e the chain leaves in;
-//   e == k, or no such pass and k == niter (the iterate after niter updates is returned untested): the run was the reference's -- done;
-//   e <  k: re-run with e updates (exact);   no such pass and k < niter: re-run with all niter updates -- that run's objectives give e exactly.
-// At most three rounds settle every chain (prediction, full, exact); kc[c] = -1 marks a settled chain, whose workgroups return at once.
-__global__ void tv_rt_begin_kernel(int64_t n, const int* __restrict__ pred, int* __restrict__ kc, double* __restrict__ obj, int stride, int niter) {
+//   e == k, or no such pass and k == niter (the iterate after niter updates is returned untested): the run was the reference's -- settled;
+//   e <  k: run again with e updates (exact, settled after it);
+//   no such pass and k < niter: the chain leaves later -- run again with k + 1 updates (pass counts wander by one between MYULA iterates), and if that
+//   is still not it, with all niter (whose objectives show e exactly), then with e.
+// Four rounds settle every chain.  kc[c] = -1 marks a settled chain, whose workgroups return at once.
+// A chained prox (more than 10 updates: links of 10 handing the dual state over in two ping-pong buffers) does not start again from its first
+// link: the links below `start[c]` keep their result of the earlier round.  What survives a run whose last link was j_k (it wrote no state): the
+// states after links j_k - 1 and j_k - 2 -- so a re-run can begin at link j_k (always: its input state is intact) or at j_k - 1 (when the run
+// itself began at or before it), else at link 0.  The objectives below the first re-run link stay as they are, the others are cleared.
+// (start[c] also carries, in bit 30, "the count of this run is known to be the exit pass": such a run settles the chain without a second look --
+// the objective of the iterate a run returns is summed by the combine wave, that of the same iterate inside a longer run by a TV stage, and the two
+// sums differ in their last bits: a chain sitting on the threshold could otherwise be sent back and forth.)
+constexpr int kRtExact = 1 << 30;
+__global__ void tv_rt_begin_kernel(int64_t n, const int* __restrict__ pred, int* __restrict__ kc, int* __restrict__ start, double* __restrict__ obj,
+                                   int stride, int niter) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
   const int k = pred[c];
   kc[c] = (k >= 1 && k <= niter) ? k : niter;
+  start[c] = 0;
   for (int j = 0; j <= niter; ++j) obj[c * stride + j] = 0.0;
 }
-__global__ void tv_rt_decide_kernel(int64_t n, int* __restrict__ kc, int* __restrict__ pred, double* __restrict__ obj, int stride, int niter, double rtol,
-                                    unsigned long long* __restrict__ reruns) {
+__global__ void tv_rt_decide_kernel(int64_t n, int* __restrict__ kc, int* __restrict__ start, int* __restrict__ pred, double* __restrict__ obj, int stride,
+                                    int niter, double rtol, int round, unsigned long long* __restrict__ reruns) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
   const int k = kc[c];
   if (k < 0) return;
+  if (start[c] & kRtExact) { pred[c] = k; kc[c] = -1; return; }
   double* o = obj + c * stride;
   int e = 0;
   const int jmax = k < niter - 1 ? k : niter - 1;
@@ -808,16 +821,28 @@ __global__ void tv_rt_decide_kernel(int64_t n, int* __restrict__ kc, int* __rest
     if (rel < rtol) { e = j; break; }
   }
   if (e == k || (e == 0 && k == niter)) { pred[c] = k; kc[c] = -1; return; }
-  kc[c] = e > 0 ? e : niter;
-  for (int j = 0; j <= niter; ++j) o[j] = 0.0;
+  const int s = start[c], jk = (k - 1) / 10;
+  int nk, ns;
+  if (e > 0) {                    // left earlier than predicted: exact
+    nk = e;
+    const int je = (e - 1) / 10;
+    ns = je == jk ? jk : ((je == jk - 1 && s <= jk - 1) ? jk - 1 : 0);
+  } else {                        // leaves later
+    nk = round == 0 ? (k + 1 < niter ? k + 1 : niter) : niter;
+    ns = jk;
+  }
+  kc[c] = nk;
+  start[c] = ns | (e > 0 ? kRtExact : 0);
+  for (int j = 10 * ns; j <= niter; ++j) o[j] = 0.0;
   if (reruns) atomicAdd(reruns, 1ull);
 }
-hipError_t launch_tv_rt_begin(int64_t n, const int* pred, int* kc, double* obj, int stride, int niter, hipStream_t st) {
-  hipLaunchKernelGGL(tv_rt_begin_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, n, pred, kc, obj, stride, niter);
+hipError_t launch_tv_rt_begin(int64_t n, const int* pred, int* kc, int* start, double* obj, int stride, int niter, hipStream_t st) {
+  hipLaunchKernelGGL(tv_rt_begin_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, n, pred, kc, start, obj, stride, niter);
   return hipGetLastError();
 }
-hipError_t launch_tv_rt_decide(int64_t n, int* kc, int* pred, double* obj, int stride, int niter, double rtol, unsigned long long* reruns, hipStream_t st) {
-  hipLaunchKernelGGL(tv_rt_decide_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, n, kc, pred, obj, stride, niter, rtol, reruns);
+hipError_t launch_tv_rt_decide(int64_t n, int* kc, int* start, int* pred, double* obj, int stride, int niter, double rtol, int round,
+                               unsigned long long* reruns, hipStream_t st) {
+  hipLaunchKernelGGL(tv_rt_decide_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, n, kc, start, pred, obj, stride, niter, rtol, round, reruns);
   return hipGetLastError();
 }
 

@@ -277,7 +277,12 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
   static_assert(D >= KT + 1, "the blur pipeline reads ring rows at least one tick old");
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // `wave` = the ROLE index used below (0 = L, 1 .. NT = T, NT + 1 = C, NT + 2 = N).  Hardware waves w and w + 4 share a SIMD.  In the RT kernels the
+  // live stages are a prefix -- a typical chain runs 3 to 5 of the 10 (waves T1, T2) with the objective sums on top, the other T waves only
+  // pass the dual on -- so the combine wave (heavier there: it forms the objective of the iterate it returns) swaps places with T4: SIMD loads
+  // L + C | T1 + T5 | T2 + T4 | T3 + N instead of L + T4 | T1 + T5 | T2 + C | T3 + N.
+  const int hw_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = (RT && K == 10) ? (hw_wave == 4 ? 6 : (hw_wave == 6 ? 4 : hw_wave)) : hw_wave;
   const int chain = blockIdx.x;
   const int H = A.H, W = A.W;
   // per-chain exit: live stages of this launch, and whether this link only advances the dual state of this chain (it leaves in a later link)
@@ -286,6 +291,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
   if constexpr (RT) {
     const int kc_g = __builtin_amdgcn_readfirstlane(A.rt_kc[chain]);
     if (kc_g <= A.rt_base) return;                   // whole workgroup, before any barrier: left in an earlier link, or no run needed
+    if (CHAIN && A.rt_start && A.rt_base < K * (__builtin_amdgcn_readfirstlane(A.rt_start[chain]) & 0xFFFF)) return;   // this link's work of an earlier round stands
     kc = min(kc_g - A.rt_base, K);
     state_only = CHAIN && kc_g > A.rt_base + K;
   }
@@ -790,20 +796,34 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
         }
       }
       if (A.ncvx_kind == LMC_NCVX_MC_TV) {   // - lambda * A^T(A x / max(|A x|, gamma))  (algs.py:273-277, 291), added to the gradient
-        // rows o-1 (kept in registers: its ring slot is being overwritten by row t this very tick), o, o+1 (ring)
-        float xp[PXL];
+        // v = A x / max(|A x|, gamma) is formed ONCE per pixel, row by row: (vx, vy) of row o from ring rows o, o + 1; A^T v at (o, j) = -((vx[o][j] -
+        // vx[o-1][j]) + (vy[o][j] - vy[o][j-1])) with vx of the previous row kept in registers.  The same values, operation for operation, as
+        // mc_tv_grad (lmc_device.h) recomputes per pixel for its three weights -- a third of the square roots and reciprocals (round 3: the
+        // per-pixel form made this wave the slowest of the workgroup, 3.0 ms per launch against 1.75 without the term).
+        float xp[PXL], vx[PXL], vy[PXL];
         prow_load<PXL>(xp, ring_row(o + 1), lane);
-        const float xm_r = dpp_right0(xprev[0]), x0_l = dpp_left0(xo[PXL - 1]), x0_r = dpp_right0(xo[0]),
-                    xp_l = dpp_left0(xp[PXL - 1]);
+        const float x0_r = dpp_right0(xo[0]);
+        const bool an = A.ncvx_gamma < 0.f, rowin = o >= 0 && o < H, down = o + 1 < H;
+        const float gth = fabsf(A.ncvx_gamma);
 #pragma unroll
         for (int j = 0; j < PXL; ++j) {
-          const int col = c0 + j;
-          gv[j] -= A.ncvx_lambda * mc_tv_grad(xprev[j], j == PXL - 1 ? xm_r : xprev[j + 1], j == 0 ? x0_l : xo[j - 1], xo[j],
-                                              j == PXL - 1 ? x0_r : xo[j + 1], j == 0 ? xp_l : xp[j - 1], xp[j], o > 0, o + 1 < H, col > 0,
-                                              col + 1 < W, A.ncvx_gamma);
+          const float dx = (rowin && down) ? xp[j] - xo[j] : 0.f;
+          const float dy = (rowin && c0 + j + 1 < W) ? (j == PXL - 1 ? x0_r : xo[j + 1]) - xo[j] : 0.f;
+          if (an) {
+            vx[j] = __builtin_amdgcn_rcpf(fmaxf(fabsf(dx), gth)) * dx;
+            vy[j] = __builtin_amdgcn_rcpf(fmaxf(fabsf(dy), gth)) * dy;
+          } else {
+            const float w = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)), gth));
+            vx[j] = w * dx;
+            vy[j] = w * dy;
+          }
         }
+        const float vy_l = dpp_left0(vy[PXL - 1]);
 #pragma unroll
-        for (int j = 0; j < PXL; ++j) xprev[j] = xo[j];
+        for (int j = 0; j < PXL; ++j) {
+          gv[j] -= A.ncvx_lambda * -((vx[j] - xprev[j]) + (vy[j] - (j == 0 ? vy_l : vy[j - 1])));
+          xprev[j] = vx[j];          // (xprev: vx of the previous row)
+        }
       }
       if (A.g_out && o >= 0 && o < H) {   // isotropic TV of the input image, row o: forward differences, zero across the last row / column
         float xq[PXL];

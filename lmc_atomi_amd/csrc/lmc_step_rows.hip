@@ -21,12 +21,27 @@ namespace lmc {
 #ifndef LMC_ROWS_PF
 #define LMC_ROWS_PF 4
 #endif
+#ifndef LMC_ROWS_PF4
+#define LMC_ROWS_PF4 3
+#endif
+#ifndef LMC_ROWS_PF7
+#define LMC_ROWS_PF7 2
+#endif
+#ifndef LMC_ROWS_YD7
+#define LMC_ROWS_YD7 0
+#endif
 
 template <int PXL, int KT>
 struct RowsGeom {
   static constexpr int HW = (KT - 1) / 2;         // taps are centred: window c-HW .. c+HW
   static constexpr int LAG = KT - 1;              // output row = input row - LAG
-  static constexpr int PF = 8 - LAG < LMC_ROWS_PF ? 8 - LAG : LMC_ROWS_PF;   // x rows fetched ahead; PF + LAG <= 8 keeps row o's slot intact
+  // x rows fetched ahead; PF + LAG <= 8 keeps row o's slot intact.  The depth is what the register file allows without spilling (scratch sizes are
+  // fenced by tests/test_kernel_resources.py).  At 7 taps and 8 pixels per lane three rings of 7-8 rows x 8 pixels leave little: x rows 2 steps ahead
+  // and the observation row requested in the step that uses it (measured at 512 x 512 x 1024, 7 x 7 box + l2 prior: 0.600 ms per launch; x 1 ahead /
+  // y 1 ahead 0.629; x 1 / y 0: 0.665; round 2's 2 / 1 with 23 spilled VGPRs: 0.647), 1 ahead for the 6 x 6 box (window 0..5), which still spilled at 2
+  static constexpr int PFW = (PXL == 8 && KT == 7) ? LMC_ROWS_PF7 : (PXL == 4 ? LMC_ROWS_PF4 : LMC_ROWS_PF);
+  static constexpr int PF = 8 - LAG < PFW ? 8 - LAG : PFW;
+  static constexpr int YD = (PXL == 8 && KT == 7) ? LMC_ROWS_YD7 : 1;        // observation rows requested this many steps ahead
 };
 
 // Row load with zero fill (predicated: here the value must stay untouched until its use several steps later -- a select applied at
@@ -74,7 +89,7 @@ __device__ __forceinline__ void rows_load4(float (&dst)[4], const float* __restr
 template <int PXL, int KT, bool DOT = false, int ULO = -1, int UHI = -1, bool AL = true>
 __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step_rows_kernel(const StepArgs P, const int band_rows, const int nbands) {
   using Gm = RowsGeom<PXL, KT>;
-  constexpr int HW = Gm::HW, LAG = Gm::LAG, PF = Gm::PF;
+  constexpr int HW = Gm::HW, LAG = Gm::LAG, PF = (PXL == 8 && KT == 7 && UHI == 5 && AL) ? 1 : Gm::PF;
   constexpr bool UNI = ULO >= 0;
   static_assert(!UNI || (UHI >= ULO && UHI < KT && !DOT), "uniform-box window");
   if constexpr (DOT) {
@@ -136,7 +151,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   // Vector-memory loads return in order, so the load a step consumes must be older than the x rows still in flight for later steps:
   // the observation row is requested kYD steps ahead and first in its step (one step ahead and after the x prefetch, every step
   // waited for an HBM access issued one step earlier).
-  constexpr int kYD = 1;   // 2 was measured: no gain, and the extra ring slots cost the registers the packed build needs
+  constexpr int kYD = Gm::YD;   // 1; 2 was measured: no gain, and the extra ring slots cost the registers the packed build needs
   static_for<0, kYD>([&](auto dd) {   // observation rows of the first kYD steps (residual rows i_first - HW + d, slot (J & 3))
     constexpr int d = decltype(dd)::value;
     const int r = i_first + d - HW;
@@ -189,6 +204,9 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
         // (2u) ring of filtered rows; vertical window of residual row r: filtered rows i - UHI .. i - ULO
 #pragma unroll
         for (int k = 0; k < PXL; ++k) A[J][k] = hx[k];
+        // The window's newest row enters before the sum is used and its oldest row leaves right after (not one step later): UHI - ULO + 1 ring
+        // rows are live between steps instead of UHI - ULO + 2 -- at 7 taps and 8 pixels per lane that is the difference between fitting the
+        // 256 VGPRs of two waves per SIMD and spilling.
         if constexpr (J == 0) {          // re-form the sum directly (bounds the rounding drift of the running update)
 #pragma unroll
           for (int k = 0; k < PXL; ++k) {
@@ -198,11 +216,13 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
           }
         } else {
 #pragma unroll
-          for (int k = 0; k < PXL; ++k) Vs[k] = (Vs[k] + A[(J - ULO + 8) & 7][k]) - A[(J - 1 - UHI + 16) & 7][k];
+          for (int k = 0; k < PXL; ++k) Vs[k] += A[(J - ULO + 8) & 7][k];
         }
         const bool rowok = r >= 0 && r < H && r >= r0 - HW;      // rows before the band's first residual row: partial windows, kept out
 #pragma unroll
         for (int k = 0; k < PXL; ++k) R[k] = (rowok && colok(k)) ? fmaf(cbox, Vs[k], -yq[J & 3][k]) : 0.f;
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) Vs[k] -= A[(J - UHI + 16) & 7][k];
       } else {
       // (2) scatter into the residual accumulators of rows i-HW .. i+HW (the last one starts here)
       static_for<0, KT>([&](auto aa) {
@@ -251,7 +271,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
         constexpr int sR = (J - HW + 8) & 7;                    // slot of residual row r = i - HW
 #pragma unroll
         for (int k = 0; k < PXL; ++k) G[sR][k] = hr[k];
-        constexpr int sNew = (J - LAG - HW + UHI + 32) & 7, sOld = (J - LAG - 1 - HW + ULO + 32) & 7;
+        constexpr int sNew = (J - LAG - HW + UHI + 32) & 7;
         if constexpr (J == 0) {
 #pragma unroll
           for (int k = 0; k < PXL; ++k) {
@@ -261,7 +281,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
           }
         } else {
 #pragma unroll
-          for (int k = 0; k < PXL; ++k) Ws[k] = (Ws[k] + G[sNew][k]) - G[sOld][k];
+          for (int k = 0; k < PXL; ++k) Ws[k] += G[sNew][k];
         }
       } else {
       // (5) scatter into the gradient accumulators of rows r+HW .. r-HW, i.e. i .. i-LAG (the first one starts here)
@@ -332,6 +352,11 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
             else store4_dword_aligned(xout + go, c0 + 4 * g, st_lo, st_hi, ov[0], ov[1], ov[2], ov[3]);
           }
         }
+      }
+      if constexpr (UNI) {     // the oldest row of the gradient window leaves (see (2u))
+        constexpr int sOldNow = (J - LAG - HW + ULO + 32) & 7;
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) Ws[k] -= G[sOldNow][k];
       }
       // (7) fetch x row i + PF into the slot row i + PF - 8 has just left (its last use was step (6) above at the latest)
       {

@@ -286,7 +286,11 @@ hipError_t launch_step_tile(StepArgs a, hipStream_t st) {
   const bool tv = a.prior_kind == LMC_PRIOR_TV_ISO;
   int halo = 0;
   if (a.data_kind == LMC_DATA_BLUR) halo = max(a.blur.kh, a.blur.kw) - 1;
-  if (tv) halo = max(halo, a.tv.niter);
+  // Dual iterations spread one pixel per iteration in every direction: K iterations from the ZERO dual state leave sol^K valid on the tile when the
+  // halo is K (the first primal iterate is x itself).  A chunk that RESUMES from a stored state first forms sol^0 = x - gamma div(state), which already
+  // reaches one pixel up / left: it needs K + 1.  (Round 3: with a halo of K the final chunk's prox was wrong along the top row / left column of every
+  // tile by an amount that decays ~6x per iteration of that chunk -- 1e-3 for a last chunk of one iteration (K = 17), 1e-9 for a full one.)
+  if (tv) halo = max(halo, a.tv.niter + (a.tv_in ? 1 : 0));
   if (a.ncvx_kind != LMC_NCVX_NONE) halo = max(halo, 1);
   TilePlan tp;
   if (!plan_tiles(a.H, a.W, halo, tv, 160 * 1024, tp)) return hipErrorInvalidConfiguration;

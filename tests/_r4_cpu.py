@@ -24,14 +24,15 @@ def truth(ny, nx, seed=1234):
     return np.clip(img, 0, 255)
 
 
-def myula_tv_chains(y, h, offset, sigma, tau_reg, K, tau, gamma, n_chains, n_iters, seed0, threads, lagged=False):
+def myula_tv_chains(y, h, offset, sigma, tau_reg, K, tau, gamma, n_chains, n_iters, seed0, threads, lagged=False, rtol=0.0):
     """``n_chains`` MYULA chains (x0 = 0, blur data term, TV prior with K dual iterations) by the C twin of the checker
     (oracle/lmc_oracle_c.c, bit-identical to oracle/lmc_oracle.py) -- chain c draws its noise from ``default_rng(seed0 + c)``.
-    Returns (sum over chains and iterations of x, of x^2, count, final states)."""
+    ``rtol > 0``: the TV prox with upstream's per-image early exit -- 1e-4 is the reference AS CONFIGURED (prox_lmc_deconv.py:122 leaves
+    pyproximal.TV's default in force).  Returns (sum over chains and iterations of x, of x^2, count, final states)."""
     from oracle import lmc_oracle_c as OC
     H, W = y.shape
     K_eff = K - 1 if lagged else K
-    prior = {"kind": "tv", "sigma": tau_reg, "niter": K_eff, "t": gamma} if K_eff > 0 else {"kind": "none"}
+    prior = {"kind": "tv", "sigma": tau_reg, "niter": K_eff, "t": gamma, "rtol": rtol} if K_eff > 0 else {"kind": "none"}
     rngs = [np.random.default_rng(seed0 + c) for c in range(n_chains)]
     xi = np.empty((n_chains, H, W))
     x = np.zeros((n_chains, H, W))

@@ -51,9 +51,9 @@ def _problem(shape, seed=0):
     return img, h, y
 
 
-def _gpu_myula(la, shape, h, y, K, C, T, seed, lagged=False, warm=False):
+def _gpu_myula(la, shape, h, y, K, C, T, seed, lagged=False, warm=False, rtol=0.0):
     pf = la.L2(Op=la.Convolve2D(shape, h, offset=(2, 2)), b=y, sigma=1 / SIGMA ** 2)
-    pg = la.TV(shape, sigma=TAU_REG, niter=K, lagged_output=lagged, warm=warm)
+    pg = la.TV(shape, sigma=TAU_REG, niter=K, lagged_output=lagged, warm=warm, rtol=rtol)
     smp = la.MYULASampler(pf, pg, shape, n_chains=C, tau=TAU, gamma=GAMMA, seed=seed, moments=True)
     smp.set_state(np.zeros(shape))
     smp.step(T)
@@ -102,6 +102,46 @@ def test_r4_myula_tv_256_posterior_mean_within_1e3(la, record_property):
           f"mean ratio {vfg.mean() / vfc.mean():.4f}")
     assert efin <= 1.5 * np.sqrt(2.0 / Cc + 2.0 / Cg), efin
     assert abs(vfg.mean() / vfc.mean() - 1.0) <= 0.02
+
+
+def _r4_against_the_reference_as_configured(la, record_property, shape, Cg, Cc, T, tag):
+    """CPU side: the checker WITH upstream's early exit (rtol = 1e-4: what prox_lmc_deconv.py:122 leaves in force -- the chain the reference
+    actually runs; its proxes leave after about 3 of the 10 passes).  GPU side, both claims: the exact path (TV(rtol=1e-4): the exit decided
+    on the device, chain by chain) and the fixed-count fast path (every chain all 10 passes: what bench.py's headline measures)."""
+    K = 10
+    img, h, y = _problem(shape)
+    s1, s2, n, xc = R.myula_tv_chains(y, h, (2, 2), SIGMA, TAU_REG, K, TAU, GAMMA, Cc, T, seed0=5000, threads=_cores(), rtol=1e-4)
+    mc_ = s1 / n
+    Ch = max(32, Cc // 8)
+    s1h, _, nh, _ = R.myula_tv_chains(y, h, (2, 2), SIGMA, TAU_REG, K, TAU, GAMMA, Ch, T, seed0=9000, threads=_cores(), rtol=1e-4)
+    mc_cpu = rel(s1h / nh, mc_) * np.sqrt(float(Ch) / (Cc + Ch)) / np.sqrt(1 + float(Ch) / Cc)
+    vfc = xc.var(axis=0)
+    for name, rtol in (("exact", 1e-4), ("fixed", 0.0)):
+        m1, _, st1, kn = _gpu_myula(la, shape, h, y, K, Cg // 2, T, seed=11, rtol=rtol)
+        m2, _, st2, _ = _gpu_myula(la, shape, h, y, K, Cg // 2, T, seed=12, rtol=rtol)
+        assert ("per-chain exit" in kn) == (rtol > 0), kn
+        mg, mc_gpu = 0.5 * (m1 + m2), 0.5 * rel(m1, m2)
+        err = rel(mg, mc_)
+        record_property(f"r4_{tag}_{name}_rel_l2_mean", float(err))
+        print(f"R4 {tag} {shape} vs the reference as configured (rtol 1e-4), GPU {name}: rel-L2(mean) = {err:.3e}; MC error gpu {mc_gpu:.2e}, cpu {mc_cpu:.2e}")
+        assert np.hypot(mc_gpu, mc_cpu) < 7e-4, (mc_gpu, mc_cpu)
+        assert err <= 1e-3, (name, err)                                          # north star
+        assert err <= 3.0 * np.hypot(mc_gpu, mc_cpu) + 1.5e-4, (name, err, mc_gpu, mc_cpu)   # no bias beyond the Monte-Carlo error (+ the 8e-5 of the fixed count)
+        vfg = np.concatenate([st1, st2]).var(axis=0)                            # across-chain variance of the final iterate
+        efin = rel(vfg, vfc)
+        record_property(f"r4_{tag}_{name}_rel_l2_var_final", float(efin))
+        assert efin <= 1.5 * np.sqrt(2.0 / Cc + 2.0 / Cg), (name, efin)
+        assert abs(vfg.mean() / vfc.mean() - 1.0) <= 0.03, (name, vfg.mean() / vfc.mean())
+
+
+def test_r4_myula_tv_256_against_the_reference_as_configured(la, record_property):
+    _r4_against_the_reference_as_configured(la, record_property, (256, 256), 4096, 512, 60, "myula256")
+
+
+def test_r4_myula_tv_512x512_1024_chains_north_star_size(la, record_property):
+    """BASELINE north_star: "posterior-mean within 1e-3 rel-L2 of reference" at 512 x 512 x 1024 chains -- the sentence as a test.  CPU: 320 chains of
+    the C twin on the box's host cores (about a minute)."""
+    _r4_against_the_reference_as_configured(la, record_property, (512, 512), 1024, 320, 60, "myula512")
 
 
 def test_r4_ulpda_64_posterior_mean(la, record_property):
