@@ -58,8 +58,13 @@ typedef enum lmc_prior_kind {
   LMC_PRIOR_TV_ISO = 3, /* g = sigma TV_iso(x)      : tv_niter FGP dual iterations (pyproximal.TV, prox_lmc_deconv.py:122);
                          *  in ULPDA: g o A with g = sigma*L21 (prox_lmc_deconv.py:116), dual prox = l2-ball projection */
   LMC_PRIOR_TV_ANISO = 4, /* ULPDA / energies only: g o A with g = sigma*L1 (prox_lmc_deconv.py:119), dual prox = clip */
-  LMC_PRIOR_HAAR_L1 = 5  /* g = sigma * || detail coefficients of the 3-level orthonormal Haar transform of x ||_1 (BASELINE
+  LMC_PRIOR_HAAR_L1 = 5, /* g = sigma * || detail coefficients of the 3-level orthonormal Haar transform of x ||_1 (BASELINE
                           * config 5; no counterpart in the reference): prox = W^T soft(W x, t*sigma); H, W multiples of 8 */
+  LMC_PRIOR_EPROX = 6    /* (ABI 3) a separable prior whose prox is one of the closed forms of prox.py (lmc_eprox_kind below; prox.py:18-85, used
+                          * inside the reference's samplers at prox_lmc.py:106,115): prox(x) = prox_X(x; p0, p1) pixel by pixel, evaluated inside
+                          * the fused step kernel.  lmc_problem.eprox_kind / eprox_p0 / eprox_p1; eprox_scale_mask bit i set = parameter i is
+                          * multiplied by the prox parameter (epsg * gamma in MYULA) -- e.g. prox_laplace(x, gamma * lam): p0 = lam, mask = 1.
+                          * MYULA / MYMALA steps and lmc_fused_eval; its value g(x) is not defined for every family: lmc_energies returns g = 0. */
 } lmc_prior_kind;
 
 typedef enum lmc_ncvx_kind {
@@ -154,7 +159,10 @@ typedef struct lmc_problem {
   int32_t moments_overlap;
   int32_t moments_bg_workgroups;
   int32_t graph_replay;
-  int32_t reserved3[2];
+  /* LMC_PRIOR_EPROX */
+  int32_t eprox_kind;             /* lmc_eprox_kind */
+  float eprox_p0, eprox_p1;
+  int32_t eprox_scale_mask;
 } lmc_problem;
 
 /* ---- library ------------------------------------------------------------------------- */

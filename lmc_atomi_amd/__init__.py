@@ -5,7 +5,8 @@ is missing or no GPU is present."""
 from . import _capi
 from ._capi import LMCError
 from .operators import Convolve2D, Diagonal, Gradient, Identity, LinearOperator
-from .proximal import L1, L2, L21, TV, L2_ncvx_tv, WaveletL1, ProxOperator, fgp_betas
+from .proximal import (L1, L2, L21, TV, L2_ncvx_tv, WaveletL1, ProxOperator, fgp_betas, ElementwiseProx, Laplace, UncenteredLaplace, Gaussian,
+                       GenGaussian, Huber, SmoothedLaplace)
 from .algs import (MYULAResult, MYULASampler, MYMALASampler, MoreauYosidaUnadjustedLangevin, MoreauYosidaMetropolisAdjustedLangevin, ULPDASampler,
                    UnadjustedLangevinPrimalDual, mean_var_from_moments,
                    set_step_variant, set_cg_tolerance)

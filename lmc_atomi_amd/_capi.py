@@ -15,7 +15,7 @@ ABI_VERSION = 3
 
 # enums (include/lmc_atomi.h)
 DATA_NONE, DATA_IDENTITY, DATA_BLUR, DATA_MASK = 0, 1, 2, 3
-PRIOR_NONE, PRIOR_L2, PRIOR_L1, PRIOR_TV_ISO, PRIOR_TV_ANISO, PRIOR_HAAR_L1 = 0, 1, 2, 3, 4, 5
+PRIOR_NONE, PRIOR_L2, PRIOR_L1, PRIOR_TV_ISO, PRIOR_TV_ANISO, PRIOR_HAAR_L1, PRIOR_EPROX = 0, 1, 2, 3, 4, 5, 6
 NOISE_PHILOX, NOISE_INJECTED, NOISE_NONE = 0, 1, 2
 NCVX_NONE, NCVX_MC_TV, NCVX_ME_TV, NCVX_MC_TV_ANISO = 0, 1, 2, 3
 MAX_BLUR = 9
@@ -65,7 +65,7 @@ class lmc_problem(C.Structure):
         ("moments_overlap", C.c_int32),
         ("moments_bg_workgroups", C.c_int32),
         ("graph_replay", C.c_int32),
-        ("reserved3", C.c_int32 * 2),
+        ("eprox_kind", C.c_int32), ("eprox_p0", C.c_float), ("eprox_p1", C.c_float), ("eprox_scale_mask", C.c_int32),
     ]
 
 

@@ -78,6 +78,8 @@ struct Problem {
   int tv_exit_path = 0;     // 1: always pass by pass
   int iters_per_launch = 0, moments_overlap = 0, moments_bg_wgs = 0, graph_replay = 0;   // launch policy (0 = library decides; fixed at sampler creation)
   int cheb_pair = 1;        // two Chebyshev iterations per launch: 0 never, 1 where they pay, 2 wherever covered
+  int eprox_kind = 0, eprox_mask = 0;   // LMC_PRIOR_EPROX: closed form, which parameters scale with the prox parameter
+  float eprox_p0 = 0.f, eprox_p1 = 0.f;
   int variant = 0;          // 0: the library default (g_variant)
   float implicit_tol = 0.f; // 0: the library default (g_cg_tol); < 0: disabled
 };
@@ -225,6 +227,12 @@ int load_problem(const lmc_problem* p, Problem& q) {
   q.prior_sigma = p->prior_sigma;
   switch (p->prior_kind) {
     case LMC_PRIOR_NONE: case LMC_PRIOR_L2: case LMC_PRIOR_L1: case LMC_PRIOR_TV_ANISO: break;
+    case LMC_PRIOR_EPROX:
+      if (p->eprox_kind < 0 || p->eprox_kind > LMC_EPROX_LAPLACE_CONJ) return fail(LMC_E_INVALID, "unknown eprox_kind %d", p->eprox_kind);
+      if (p->eprox_scale_mask < 0 || p->eprox_scale_mask > 3) return fail(LMC_E_INVALID, "eprox_scale_mask must be 0..3");
+      if (!(p->eprox_p0 == p->eprox_p0) || !(p->eprox_p1 == p->eprox_p1)) return fail(LMC_E_INVALID, "eprox parameter is NaN");
+      q.eprox_kind = p->eprox_kind; q.eprox_mask = p->eprox_scale_mask; q.eprox_p0 = p->eprox_p0; q.eprox_p1 = p->eprox_p1;
+      break;
     case LMC_PRIOR_HAAR_L1:
       if ((p->H & 7) || (p->W & 7)) return fail(LMC_E_UNSUPPORTED, "the Haar-l1 prior needs H and W to be multiples of 8 (got %dx%d)", p->H, p->W);
       break;
@@ -240,7 +248,7 @@ int load_problem(const lmc_problem* p, Problem& q) {
       break;
     default: return fail(LMC_E_INVALID, "unknown prior_kind %d", p->prior_kind);
   }
-  if (p->prior_kind != LMC_PRIOR_NONE && !(p->prior_sigma >= 0.f)) return fail(LMC_E_INVALID, "prior_sigma must be >= 0");
+  if (p->prior_kind != LMC_PRIOR_NONE && p->prior_kind != LMC_PRIOR_EPROX && !(p->prior_sigma >= 0.f)) return fail(LMC_E_INVALID, "prior_sigma must be >= 0");
   if (p->ncvx_kind != LMC_NCVX_NONE) {
     if (p->ncvx_kind != LMC_NCVX_MC_TV && p->ncvx_kind != LMC_NCVX_ME_TV && p->ncvx_kind != LMC_NCVX_MC_TV_ANISO)
       return fail(LMC_E_INVALID, "unknown ncvx_kind %d", p->ncvx_kind);
@@ -292,6 +300,11 @@ int make_step_args(const Problem& q, float a, float t, float b, float pt, float 
   if (A.prior_kind == LMC_PRIOR_HAAR_L1) A.prior_p0 = pt * q.prior_sigma;  // soft threshold of the detail coefficients
   if (A.prior_kind == LMC_PRIOR_L2) A.prior_p0 = 1.f / (1.f + pt * q.prior_sigma);
   if (A.prior_kind == LMC_PRIOR_L1) A.prior_p0 = pt * q.prior_sigma;
+  if (A.prior_kind == LMC_PRIOR_EPROX) {     // prox.py closed forms: the parameters the mask names scale with the prox parameter
+    A.eprox_kind = q.eprox_kind;
+    A.prior_p0 = (q.eprox_mask & 1) ? pt * q.eprox_p0 : q.eprox_p0;
+    A.prior_p1 = (q.eprox_mask & 2) ? pt * q.eprox_p1 : q.eprox_p1;
+  }
   if (A.prior_kind == LMC_PRIOR_TV_ISO) {
     const float gam = pt * q.prior_sigma;
     if (!(gam > 0.f)) return fail(LMC_E_INVALID, "TV prox parameter must be > 0 (got %g)", (double)gam);

@@ -33,7 +33,9 @@ struct StepArgs {
   const float* mask;
   BlurTaps blur;
   int prior_kind;
-  float prior_p0;     // L2: 1/(1+t*sigma) ; L1: threshold t*sigma
+  float prior_p0;     // L2: 1/(1+t*sigma) ; L1: threshold t*sigma ; EPROX: first parameter of the closed form
+  float prior_p1;     // EPROX: second parameter
+  int eprox_kind;     // EPROX: lmc_eprox_kind
   TvIter tv;
   int ncvx_kind;             // LMC_NCVX_*: extra term of the data gradient (algs.py:270-291)
   float ncvx_lambda, ncvx_inv_gamma, ncvx_gamma;

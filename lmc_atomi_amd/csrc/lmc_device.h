@@ -235,6 +235,56 @@ __device__ __forceinline__ float gather_last(float acc, float v) {
                                                               0x100 + N, 0xf, 1 << ((15 - N) >> 2), false));
 }
 
+// ---- closed-form elementwise proxes (prox.py:9-85): the functional plugin surface (lmc_prox_elementwise) and the LMC_PRIOR_EPROX priors of the
+// fused step kernels ----------------------------------------------------------------------------------------------------------------------
+struct EproxParams { float p0, p1; };
+
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
+__device__ __forceinline__ float soft(float x, float t) { return copysignf(fmaxf(fabsf(x) - t, 0.f), x); }
+
+__device__ __forceinline__ float eprox(int kind, float x, EproxParams q) {
+  const float g = q.p0;
+  switch (kind) {
+    case LMC_EPROX_LAPLACE: return sgn(x) * fmaxf(fabsf(x) - g, 0.f);
+    case LMC_EPROX_UNCENTERED_LAPLACE: { const float d = x - q.p1; return q.p1 + sgn(d) * fmaxf(fabsf(d) - g, 0.f); }
+    case LMC_EPROX_GAUSSIAN: return x / (2.f * g + 1.f);
+    case LMC_EPROX_GEN_GAUSSIAN_4_3: {
+      const float xi = sqrtf(x * x + 256.f * g * g * g / 729.f);
+      return x + 4.f * g / (3.f * cbrtf(2.f)) * (cbrtf(xi - x) - cbrtf(xi + x));
+    }
+    case LMC_EPROX_GEN_GAUSSIAN_3_2:
+      return x + 9.f * g * g * sgn(x) * (1.f - sqrtf(1.f + 16.f * fabsf(x) / (9.f * g * g))) / 8.f;
+    case LMC_EPROX_GEN_GAUSSIAN_3: return sgn(x) * (sqrtf(1.f + 12.f * g * fabsf(x)) - 1.f) / (6.f * g);
+    case LMC_EPROX_GEN_GAUSSIAN_4: {
+      const float xi = sqrtf(x * x + 1.f / (27.f * g));
+      return cbrtf((xi + x) / (8.f * g)) - cbrtf((xi - x) / (8.f * g));
+    }
+    case LMC_EPROX_HUBER: {
+      const float t = q.p1;
+      return fabsf(x) <= g * (2.f * t + 1.f) / sqrtf(2.f * t) ? x / (2.f * t + 1.f) : x - g * sqrtf(2.f * t) * sgn(x);
+    }
+    case LMC_EPROX_SMOOTHED_LAPLACE: {
+      const float ax = fabsf(x), u = g * ax - g * g - 1.f;
+      return sgn(x) * (u + sqrtf(u * u + 4.f * g * ax)) / (2.f * g);
+    }
+    case LMC_EPROX_EXP: return x >= g ? x - g : 0.f;
+    case LMC_EPROX_GAMMA: { const float d = x - q.p0; return (d + sqrtf(d * d + 4.f * q.p1)) * 0.5f; }
+    case LMC_EPROX_CHI: return (x + sqrtf(x * x + 8.f * q.p0)) * 0.25f;
+    case LMC_EPROX_UNIFORM: return fminf(fmaxf(x, -q.p0), q.p0);
+    case LMC_EPROX_TRIANGULAR: {
+      const float o1 = q.p0, o2 = q.p1;
+      if (x < 1.f / o1) return (x + o1 + sqrtf((x - o1) * (x - o1) + 4.f)) * 0.5f;
+      if (x > 1.f / o2) return (x + o2 + sqrtf((x - o2) * (x - o2) + 4.f)) * 0.5f;
+      return 0.f;
+    }
+    case LMC_EPROX_LAPLACE_CONJ: {  // x - g * prox_laplace(x/g, 1/g)
+      const float z = x / g;
+      return x - g * (sgn(z) * fmaxf(fabsf(z) - 1.f / g, 0.f));
+    }
+  }
+  return x;
+}
+
 template <int I, int End, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < End) {

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
         if (PRIOR == LMC_PRIOR_HAAR_L1) px = v[r][j];
         else if (PRIOR == LMC_PRIOR_L2) px = x * P.prior_p0;
         else if (PRIOR == LMC_PRIOR_L1) px = soft_thr_b(x, P.prior_p0);
+        else if (PRIOR == LMC_PRIOR_EPROX) px = eprox(P.eprox_kind, x, EproxParams{P.prior_p0, P.prior_p1});   // closed forms of prox.py
         o[j] = fmaf(P.b, px, fmaf(P.s, xi[j], fmaf(P.a, x, -ts * g)));
         if constexpr (MC) {
           const float (&up)[10] = wr[r % 3], (&cu)[10] = wr[(r + 1) % 3], (&dn)[10] = wr[(r + 2) % 3];
@@ -208,6 +209,7 @@ static void launch_block_data(const StepArgs& a, int nblk, hipStream_t st) {
   switch (a.prior_kind) {
     case LMC_PRIOR_L2: hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_L2>), dim3(nblk), dim3(256), 0, st, a); break;
     case LMC_PRIOR_L1: hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_L1>), dim3(nblk), dim3(256), 0, st, a); break;
+    case LMC_PRIOR_EPROX: hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_EPROX>), dim3(nblk), dim3(256), 0, st, a); break;
     case LMC_PRIOR_HAAR_L1:
       if (a.ncvx_kind == LMC_NCVX_MC_TV) hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_HAAR_L1, true>), dim3(nblk), dim3(256), 0, st, a);
       else if (a.fused_iters == 2) hipLaunchKernelGGL((myula_step_block_kernel<DATA, LMC_PRIOR_HAAR_L1, false, 2>), dim3(nblk), dim3(256), 0, st, a);

@@ -277,12 +277,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
   static_assert(D >= KT + 1, "the blur pipeline reads ring rows at least one tick old");
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
-  // `wave` = the ROLE index used below (0 = L, 1 .. NT = T, NT + 1 = C, NT + 2 = N).  Hardware waves w and w + 4 share a SIMD.  In the RT kernels the
-  // live stages are a prefix -- a typical chain runs 3 to 5 of the 10 (waves T1, T2) with the objective sums on top, the other T waves only
-  // pass the dual on -- so the combine wave (heavier there: it forms the objective of the iterate it returns) swaps places with T4: SIMD loads
-  // L + C | T1 + T5 | T2 + T4 | T3 + N instead of L + T4 | T1 + T5 | T2 + C | T3 + N.
   const int hw_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wave = (RT && K == 10) ? (hw_wave == 4 ? 6 : (hw_wave == 6 ? 4 : hw_wave)) : hw_wave;
   const int chain = blockIdx.x;
   const int H = A.H, W = A.W;
   // per-chain exit: live stages of this launch, and whether this link only advances the dual state of this chain (it leaves in a later link)
@@ -294,6 +289,15 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     if (CHAIN && A.rt_start && A.rt_base < K * (__builtin_amdgcn_readfirstlane(A.rt_start[chain]) & 0xFFFF)) return;   // this link's work of an earlier round stands
     kc = min(kc_g - A.rt_base, K);
     state_only = CHAIN && kc_g > A.rt_base + K;
+  }
+  // `wave` = the ROLE index used below (0 = L, 1 .. NT = T, NT + 1 = C, NT + 2 = N).  Hardware waves w and w + 4 share a SIMD: L + T4 | T1 + T5 |
+  // T2 + C | T3 + N.  In an RT launch the live stages are a prefix: a typical chain runs 3 to 5 of the 10 (waves T1, T2, half of T3), each with the
+  // objective sums on top, the other T waves only pass the dual on, and the combine wave forms the objective of the iterate it returns.  A chain
+  // with few live stages therefore pairs every heavy wave with a pass-through one: L + N | T1 + T4 | T2 + T3 | C + T5 (measured: DESIGN 3.0r).
+  int wave = hw_wave;
+  if constexpr (RT && K == 10) {
+    if (kc <= 4) wave = hw_wave == 3 ? 6 : hw_wave == 4 ? 7 : hw_wave == 5 ? 4 : hw_wave == 6 ? 3 : hw_wave == 7 ? 5 : hw_wave;
+    else wave = hw_wave == 4 ? 6 : hw_wave == 6 ? 4 : hw_wave;        // more live stages: L + C | T1 + T5 | T2 + T4 | T3 + N
   }
   // column strip of this workgroup (blockIdx.y; one strip = the whole row when W <= 64 PXL): c0 is a GLOBAL column, LDS rows are indexed by lane
   constexpr int HALO = pipe_halo(K, KT, PXL);

@@ -160,6 +160,7 @@ __global__ __launch_bounds__(kPtThreads) void myula_step_point_kernel(const Step
       float px = x;
       if (P.prior_kind == LMC_PRIOR_L2) px = x * P.prior_p0;
       else if (P.prior_kind == LMC_PRIOR_L1) px = copysignf(fmaxf(fabsf(x) - P.prior_p0, 0.f), x);
+      else if (P.prior_kind == LMC_PRIOR_EPROX) px = eprox(P.eprox_kind, x, EproxParams{P.prior_p0, P.prior_p1});
       if (P.prox_ext) px = P.prox_ext[(size_t)chain * img + gi];
       float nz = xi[j];
       if (P.noise_mode == LMC_NOISE_INJECTED) nz = P.noise[(size_t)chain * img + gi];

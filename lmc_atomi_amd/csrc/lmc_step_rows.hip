@@ -86,7 +86,9 @@ __device__ __forceinline__ void rows_load4(float (&dst)[4], const float* __restr
 // elsewhere (same window for rows and columns), so every 1-D pass is a sliding window sum: 2 operations per pixel instead of KT (horizontal: the
 // first pixel of a lane directly, the next ones by +new -old; vertical: a running sum over a ring of the horizontally filtered rows, re-formed
 // directly every 8th row so that rounding cannot drift).  The scale c_u^2 c_v^2 sigma_f is applied once.  Same update to rounding (tests).
-template <int PXL, int KT, bool DOT = false, int ULO = -1, int UHI = -1, bool AL = true>
+// EP: the prior is one of the closed-form elementwise proxes of prox.py (LMC_PRIOR_EPROX) -- instantiations of their own, so that the fifteen
+// closed forms (cube roots, square roots) cost the register-tight l2 / l1 / ready-made-prox kernels nothing.
+template <int PXL, int KT, bool DOT = false, int ULO = -1, int UHI = -1, bool AL = true, bool EP = false>
 __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step_rows_kernel(const StepArgs P, const int band_rows, const int nbands) {
   using Gm = RowsGeom<PXL, KT>;
   constexpr int HW = Gm::HW, LAG = Gm::LAG, PF = (PXL == 8 && KT == 7 && UHI == 5 && AL) ? 1 : Gm::PF;
@@ -333,7 +335,8 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
               float gr = UNI ? (P.sigma_f * cbox) * Ws[4 * g + q] : P.sigma_f * G[so][4 * g + q];
               if (P.extra) gr = fmaf(P.extra_coef, x - ex[q], gr);
               float px = x;
-              if (P.prior_kind == LMC_PRIOR_L2) px = x * P.prior_p0;
+              if constexpr (EP) px = eprox(P.eprox_kind, x, EproxParams{P.prior_p0, P.prior_p1});
+              else if (P.prior_kind == LMC_PRIOR_L2) px = x * P.prior_p0;
               else if (P.prior_kind == LMC_PRIOR_L1) px = copysignf(fmaxf(fabsf(x) - P.prior_p0, 0.f), x);
               if (P.prox_ext) px = pe[q];
               ov[q] = fmaf(P.a, x, fmaf(-P.t, gr, fmaf(P.b, px, P.s * xi[q])));
@@ -417,7 +420,8 @@ int centred_blur_taps(const StepArgs& a, float* uc, float* vc) { return centred_
 
 bool rows_supported(const StepArgs& a) {
   if (a.data_kind != LMC_DATA_BLUR || a.ncvx_kind != LMC_NCVX_NONE) return false;
-  if (a.prior_kind != LMC_PRIOR_NONE && a.prior_kind != LMC_PRIOR_L2 && a.prior_kind != LMC_PRIOR_L1) return false;
+  if (a.prior_kind != LMC_PRIOR_NONE && a.prior_kind != LMC_PRIOR_L2 && a.prior_kind != LMC_PRIOR_L1 && a.prior_kind != LMC_PRIOR_EPROX) return false;
+  if (a.prior_kind == LMC_PRIOR_EPROX && ((a.W & 3) || a.W > 512 || a.dot_out)) return false;      // EP instantiations: aligned rows, one strip
   if (a.tv_in || a.tv_out) return false;
   // any width: rows that are not 16-byte aligned (W % 4 != 0) go pixel by pixel, images wider than one wave (512 columns) as column strips
   if (a.W < 4 || a.W > 16384 || a.H < 1) return false;
@@ -483,6 +487,18 @@ hipError_t launch_step_rows(StepArgs a, hipStream_t st) {
   if (KT == KTT && lo == LO && hi == HI) {                                                                                   \
     hipLaunchKernelGGL((myula_step_rows_kernel<PX, KTT, false, LO, HI, ##__VA_ARGS__>), dim3(nblk), dim3(256), 0, st, a, band, nbands); \
     return hipGetLastError();                                                                                                \
+  }
+  if (a.prior_kind == LMC_PRIOR_EPROX) {     // closed-form elementwise priors: the general-taps form and the 5 x 5 uniform box, aligned rows
+    if (a.W <= 256) {
+      if (KT == 5 && lo == 0 && hi == 4) hipLaunchKernelGGL((myula_step_rows_kernel<4, 5, false, 0, 4, true, true>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+      else if (KT == 5) hipLaunchKernelGGL((myula_step_rows_kernel<4, 5, false, -1, -1, true, true>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+      else hipLaunchKernelGGL((myula_step_rows_kernel<4, 7, false, -1, -1, true, true>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+    } else {
+      if (KT == 5 && lo == 0 && hi == 4) hipLaunchKernelGGL((myula_step_rows_kernel<8, 5, false, 0, 4, true, true>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+      else if (KT == 5) hipLaunchKernelGGL((myula_step_rows_kernel<8, 5, false, -1, -1, true, true>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+      else hipLaunchKernelGGL((myula_step_rows_kernel<8, 7, false, -1, -1, true, true>), dim3(nblk), dim3(256), 0, st, a, band, nbands);
+    }
+    return hipGetLastError();
   }
   if (!al) {
     LMC_ROWS_UNI_LAUNCH(8, 5, 0, 4, false) LMC_ROWS_UNI_LAUNCH(8, 7, 0, 6, false) LMC_ROWS_UNI_LAUNCH(8, 7, 0, 5, false)

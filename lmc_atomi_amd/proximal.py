@@ -111,6 +111,10 @@ class _Problem:
         p.moments_overlap = int(opt.get("moments_overlap", 0) or 0)
         p.moments_bg_workgroups = int(opt.get("moments_bg_workgroups", 0) or 0)
         p.graph_replay = 1 if opt.get("graph_replay") else 0
+        if p.prior_kind == _capi.PRIOR_EPROX:
+            p.eprox_kind = int(prior["eprox_kind"])
+            p.eprox_p0, p.eprox_p1 = float(prior["eprox_p0"]), float(prior["eprox_p1"])
+            p.eprox_scale_mask = int(prior.get("eprox_scale_mask", 0))
         self.c = p
 
     def eval(self, x, a, t, b, pt):
@@ -340,6 +344,84 @@ class TV(ProxOperator):
 
     def prox(self, x, tau):
         return self._problem().eval(x, 0.0, 0.0, 1.0, float(tau))
+
+
+class ElementwiseProx(ProxOperator):
+    """A separable prior given by one of the closed-form proxes of the reference's ``prox.py`` (prox.py:18-85; used inside its samplers at
+    prox_lmc.py:106,115 as ``prox.prox_laplace(theta, lamda * alpha)``): ``prox(x, tau) = prox_<kind>(x, *params)`` pixel by pixel, with the
+    parameters listed in ``scaled`` multiplied by ``tau`` first.  As ``proxg`` of the MYULA samplers it is evaluated INSIDE the fused step
+    kernel (``LMC_PRIOR_EPROX``: row-streaming, register-block and tiled kernels); stand-alone it is ``lmc_prox_elementwise``.
+
+    ``kind``: 'laplace' | 'uncentered_laplace' | 'gaussian' | 'gen_gaussian_4_3' | 'gen_gaussian_3_2' | 'gen_gaussian_3' | 'gen_gaussian_4' |
+    'huber' | 'smoothed_laplace' | 'exp' | 'gamma' | 'chi' | 'uniform' | 'triangular' | 'laplace_conj' (parameter order as in prox.py).
+    The value g(x) is not defined for every family (the reference only ever uses their proxes): ``__call__`` returns 0."""
+
+    KINDS = {"laplace": (_capi.EPROX_LAPLACE, 1), "uncentered_laplace": (_capi.EPROX_UNCENTERED_LAPLACE, 2), "gaussian": (_capi.EPROX_GAUSSIAN, 1),
+             "gen_gaussian_4_3": (_capi.EPROX_GEN_GAUSSIAN_4_3, 1), "gen_gaussian_3_2": (_capi.EPROX_GEN_GAUSSIAN_3_2, 1),
+             "gen_gaussian_3": (_capi.EPROX_GEN_GAUSSIAN_3, 1), "gen_gaussian_4": (_capi.EPROX_GEN_GAUSSIAN_4, 1), "huber": (_capi.EPROX_HUBER, 2),
+             "smoothed_laplace": (_capi.EPROX_SMOOTHED_LAPLACE, 1), "exp": (_capi.EPROX_EXP, 1), "gamma": (_capi.EPROX_GAMMA, 2),
+             "chi": (_capi.EPROX_CHI, 1), "uniform": (_capi.EPROX_UNIFORM, 1), "triangular": (_capi.EPROX_TRIANGULAR, 2),
+             "laplace_conj": (_capi.EPROX_LAPLACE_CONJ, 1)}
+
+    def __init__(self, kind, *params, scaled=()):
+        super().__init__(None, False)
+        if kind not in self.KINDS:
+            raise ValueError(f"unknown closed-form prox {kind!r}")
+        self.kind = kind
+        self.code, n = self.KINDS[kind]
+        if len(params) != n:
+            raise ValueError(f"prox_{kind} takes {n} parameter(s)")
+        self.params = tuple(float(v) for v in params)
+        self.scaled = tuple(int(i) for i in scaled)
+        if any(i < 0 or i >= n for i in self.scaled):
+            raise ValueError("scaled: indices of the parameters that are multiplied by tau")
+
+    def _scaled_params(self, tau):
+        return [v * float(tau) if i in self.scaled else v for i, v in enumerate(self.params)]
+
+    def prior_descriptor(self):
+        p = self.params + (0.0,) * (2 - len(self.params))
+        return {"prior_kind": _capi.PRIOR_EPROX, "eprox_kind": self.code, "eprox_p0": p[0], "eprox_p1": p[1],
+                "eprox_scale_mask": sum(1 << i for i in self.scaled)}
+
+    def __call__(self, x):
+        return 0.0
+
+    def prox(self, x, tau):
+        xt = _dev.to_dev(x)
+        out = torch.empty_like(xt)
+        par = np.asarray(self._scaled_params(tau), dtype=np.float32)
+        _dev.run(xt, "lmc_prox_elementwise", self.code, _dev.ptr(xt), _dev.ptr(out), xt.numel(), _dev.fptr(par), par.size)
+        return _dev.like_input(out, x)
+
+
+def Laplace(lam):
+    """``lam * ||x||_1`` through ``prox_laplace(x, tau * lam)`` (prox.py:18; prox_lmc.py:106)."""
+    return ElementwiseProx("laplace", lam, scaled=(0,))
+
+
+def UncenteredLaplace(lam, mu):
+    return ElementwiseProx("uncentered_laplace", lam, mu, scaled=(0,))       # prox.py:22
+
+
+def Gaussian(lam):
+    return ElementwiseProx("gaussian", lam, scaled=(0,))                     # prox.py:26: x / (2 tau lam + 1)
+
+
+def GenGaussian(p, lam):
+    """``lam * |x|^p``, p in {4/3, 3/2, 3, 4} (prox.py:30-41)."""
+    names = {4 / 3: "gen_gaussian_4_3", 3 / 2: "gen_gaussian_3_2", 3: "gen_gaussian_3", 4: "gen_gaussian_4"}
+    if p not in names:
+        raise ValueError("p must be one of 4/3, 3/2, 3, 4")
+    return ElementwiseProx(names[p], lam, scaled=(0,))
+
+
+def Huber(gamma, tau):
+    return ElementwiseProx("huber", gamma, tau, scaled=(1,))                 # prox.py:44: tau is the prox weight
+
+
+def SmoothedLaplace(lam):
+    return ElementwiseProx("smoothed_laplace", lam, scaled=(0,))             # prox.py:52
 
 
 class WaveletL1(ProxOperator):

@@ -16,7 +16,7 @@ SCRATCH_LIMIT = 256     # bytes per lane; 256 B x 64 lanes x 8192 wave slots = 1
 
 # kernels a model of the reference's driver (prox_lmc_deconv.py:447-703: 5x5 / 6x6 / 7x7 box blurs, TV niter = 10, MC-TV, ME-TV with
 # niter_l2 = 50) reaches at 512 x 512 -- MYULA and ULPDA -- plus the BASELINE configurations (l2 prior, mask + Haar): no scratch at all
-# (template arguments: pipe <K, PXL, KT, CHAIN, WARM, AL, RT>; rows <PXL, KT, DOT, ULO, UHI, AL>)
+# (template arguments: pipe <K, PXL, KT, CHAIN, WARM, AL, RT>; rows <PXL, KT, DOT, ULO, UHI, AL, EP>)
 ZERO_SCRATCH = [
     "myula_step_pipe_kernel<10, 8, 5, false, false, true, false>",     # 5x5 blur + TV / MC-TV / ME-TV step (headline)
     "myula_step_pipe_kernel<10, 8, 7, false, false, true, false>",     # 6x6 / 7x7 blur
@@ -24,11 +24,11 @@ ZERO_SCRATCH = [
     "myula_step_pipe_kernel<10, 8, 7, false, false, true, true>",
     "myula_step_pipe_kernel<10, 8, 0, true, false, true, false>",      # links of the ME-TV inner prox
     "myula_step_pipe_kernel<10, 8, 0, true, false, true, true>",
-    "myula_step_rows_kernel<8, 5, true, -1, -1, true>",                # ULPDA: operator of the implicit step (first Chebyshev iteration, CG)
-    "myula_step_rows_kernel<8, 7, true, -1, -1, true>",
-    "myula_step_rows_kernel<8, 5, false, 0, 4, true>",                 # uniform boxes: 5x5, 6x6 (window 0..5 of 7 taps), 7x7
-    "myula_step_rows_kernel<8, 7, false, 0, 5, true>",
-    "myula_step_rows_kernel<8, 7, false, 0, 6, true>",
+    "myula_step_rows_kernel<8, 5, true, -1, -1, true, false>",                # ULPDA: operator of the implicit step (first Chebyshev iteration, CG)
+    "myula_step_rows_kernel<8, 7, true, -1, -1, true, false>",
+    "myula_step_rows_kernel<8, 5, false, 0, 4, true, false>",                 # uniform boxes: 5x5, 6x6 (window 0..5 of 7 taps), 7x7
+    "myula_step_rows_kernel<8, 7, false, 0, 5, true, false>",
+    "myula_step_rows_kernel<8, 7, false, 0, 6, true, false>",
     "myula_step_rows_pair_kernel<8>",
     "cheb_pair_kernel<8",
     "myula_step_block_kernel<3, 5, false",                             # mask + Haar
