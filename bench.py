@@ -239,8 +239,9 @@ def main():
     # one HIP-event pair per step-kernel launch (the roofline leg) -- except on small configurations, where the two event records cost
     # 6 us of a 40 us iteration (measured at 256 x 256 x 128) and would be what the bench measures: there the launch time is wall / steps
     timed_launches = args.alg == "myula" and os.environ.get("LMC_BENCH_NO_TIMING") != "1" and H * W * C > (1 << 25)
-    if timed_launches:
-        smp.enable_timing(True)
+    # Round 3: `value` is measured as the sampler runs by default -- posterior-moment reductions on a side stream under the next step kernel --
+    # and the step kernel's own launch time (the roofline leg) in ONE MORE region of K steps after the timed ones, with per-launch HIP events
+    # switched on, which also takes the reductions back in line so that the kernel is timed alone.
     regions = []                                     # (elapsed s of K steps, step-kernel ms summed over its launches, launches)
     for _ in range(max(1, args.repeats)):
         if not args.no_moments:
@@ -256,13 +257,16 @@ def main():
             te = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             el = float(te.item())
-        if timed_launches:
-            kms, nl = smp.last_step_timing()
-        else:                    # ULPDA / MYMALA are sequences of launches per iteration, small configurations are not event-timed: the whole iteration
-            kms, nl = el * 1e3, args.steps
-        regions.append((el, kms, nl))
+        regions.append((el, el * 1e3, args.steps))   # ULPDA / MYMALA are sequences of launches per iteration, small configurations are not event-timed: the whole iteration
     order = sorted(range(len(regions)), key=lambda i: regions[i][0])
     elapsed, kern_ms, launches = regions[order[len(order) // 2]]          # the median region
+    if timed_launches:           # the roofline leg: the same K steps once more, every step-kernel launch between its own pair of HIP events
+        smp.enable_timing(True)
+        sync_all()
+        smp.step(args.steps)
+        sync_all()
+        kern_ms, launches = smp.last_step_timing()
+        smp.enable_timing(False)
 
     if rank == 0:
         # HBM bytes per launch from the committed rocprofv3 PMC passes (they cannot be collected inside this process);
@@ -355,7 +359,7 @@ def main():
                 ps, rr = smp.tv_exit_stats("prior")
                 pc = np.bincount(ps.cpu().numpy(), minlength=args.tv_iters + 1)
                 out["config"]["tv_exit"] = {"passes_histogram_last_iteration": pc.tolist(), "reruns_after_round_1_2_3_4": rr,
-                                            "chain_iterations": int(C * (args.warmup + args.steps * len(regions)))}
+                                            "chain_iterations": int(C * (args.warmup + args.steps * (len(regions) + (1 if timed_launches else 0))))}
             except Exception as exc:
                 out["config"]["tv_exit"] = f"pass-by-pass path ({exc})"
         if args.ncvx_rtol and args.ncvx == "me" and args.alg == "myula":

@@ -152,7 +152,7 @@ typedef struct lmc_problem {
    *  iterations_per_launch  (LMC_ITERS_PER_LAUNCH, and the older LMC_ROWS_PAIR / LMC_BLOCK_PAIR / LMC_CHEB_PAIR): 0 = several iterations per
    *      launch where a kernel covers the configuration and the launch is large enough to pay (two MYULA iterations: separable 5 x 5 box +
    *      closed-form prior, mask + Haar; two Chebyshev iterations of the implicit step); 1 = always one; 2 = wherever covered (tests).
-   *  moments_overlap  (LMC_MOMENTS_OVERLAP): posterior-moment reductions on a side stream under the next step kernel: 0 = by size, 1 = on, -1 = off.
+   *  moments_overlap  (LMC_MOMENTS_OVERLAP): posterior-moment reductions on a side stream under the next step kernel: 0 = on (default), 1 = on, -1 = off.
    *  moments_bg_workgroups  (LMC_MOMENTS_BG_WGS): workgroups of that background reduction, 0 = by size.
    *  graph_replay  (LMC_GRAPH): 1 = replay captured hipGraphs of 8 iterations. */
   int32_t iterations_per_launch;
@@ -285,9 +285,10 @@ int lmc_sampler_set_state(lmc_sampler* s, const float* x_dev, void* stream);
 int lmc_sampler_get_state(lmc_sampler* s, float* x_dev, void* stream);
 /* Run n_iters iterations of algs.py:564-570 on every chain.  noise_dev is
  * [n_iters][n_chains][H][W] when noise_mode == LMC_NOISE_INJECTED, else NULL.
- * All work is enqueued on `stream`.  (Environment LMC_MOMENTS_OVERLAP=1 moves the posterior-moment reductions of all but the last
- * iteration of a call to an internal side stream that runs under the following step kernel; the call still returns with everything
- * it enqueued ordered before whatever the caller enqueues on `stream` next.) */
+ * All work is enqueued on `stream`.  The posterior-moment reductions of all but the last iteration of a call run on an internal side stream
+ * under the following step kernel (ABI 3: at every size; lmc_problem.moments_overlap = -1 / LMC_MOMENTS_OVERLAP=0 keeps them in line, and so
+ * does lmc_sampler_enable_timing); the call still returns with everything it enqueued ordered before whatever the caller enqueues on
+ * `stream` next. */
 int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, void* stream);
 /* iteration counter (number of completed iterations since creation / last set_iteration) */
 int64_t lmc_sampler_iteration(const lmc_sampler* s);
@@ -301,7 +302,8 @@ int lmc_sampler_energies(lmc_sampler* s, double* f_out_dev, double* g_out_dev, v
 /* the noise field xi[n_chains][H][W] the sampler draws at `iteration` (parity rung R3) */
 int lmc_sampler_noise(lmc_sampler* s, int64_t iteration, float* out_dev, void* stream);
 /* HIP-event timing of the step kernels: when enabled, lmc_sampler_step brackets EACH step-kernel
- * launch with its own event pair on the launch stream (interleaved moment reductions stay outside).
+ * launch with its own event pair on the launch stream (interleaved moment reductions stay outside, and run in line -- not on the side
+ * stream -- so that the step kernel is timed alone).
  * last_step_timing returns the summed kernel milliseconds and the number of launches of the LAST
  * lmc_sampler_step call (bench.py's roofline leg); it synchronises on the last event. */
 int lmc_sampler_enable_timing(lmc_sampler* s, int32_t on);

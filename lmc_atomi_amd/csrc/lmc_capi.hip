@@ -816,6 +816,12 @@ struct lmc_sampler {
   uint64_t count = 0;
   float* x[2] = {nullptr, nullptr};
   float* xspare = nullptr;    // third state array of the two-iterations-per-launch MYULA path (allocated at its first use)
+  // Moment reductions of the pair launches on the side stream: the iterate in between goes to one of two arrays of its own (a pair launch two
+  // launches later is the first that may write where launch n's reductions read: ev_pair[n & 1] orders that)
+  float* xmid[2] = {nullptr, nullptr};
+  hipEvent_t ev_pair[2] = {nullptr, nullptr};
+  bool pair_pending[2] = {false, false};
+  uint64_t pair_n = 0;
   int cur = 0;
   double* s1 = nullptr;
   double* s2 = nullptr;
@@ -1197,7 +1203,7 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
 void lmc_sampler_destroy(lmc_sampler* s) {
   if (!s) return;
   DeviceGuard dg(s->device);
-  for (float* b : {s->ydual2, s->xspare, s->zero_y, s->xhat, s->ydual, s->uw, s->uw2, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra, s->pxbuf,
+  for (float* b : {s->xmid[0], s->xmid[1], s->ydual2, s->xspare, s->zero_y, s->xhat, s->ydual, s->uw, s->uw2, s->rhs, s->cr, s->cp, s->cq, s->ctmp, s->xi, s->htb, s->tvstate[0], s->tvstate[1], s->extra, s->pxbuf,
                    s->mx, s->xp, s->mxp, s->tvwarm[0], s->tvwarm[1], s->rtmp})
     if (b) (void)hipFree(b);
   if (s->robj) (void)hipFree(s->robj);
@@ -1222,6 +1228,7 @@ void lmc_sampler_destroy(lmc_sampler* s) {
   if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
   if (s->ev_step) (void)hipEventDestroy(s->ev_step);
   for (hipEvent_t e : s->ev_mom) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : s->ev_pair) if (e) (void)hipEventDestroy(e);
   delete s;
 }
 
@@ -1403,7 +1410,9 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
   // iteration with 256 workgroups (16: 3.19, 64: 2.07, 128: 1.92, 256: 1.90, 512: 1.94, 1024: 1.98 ms; too few and the reduction outlasts the
   // step kernel) -- a 3.5 % gain that is left opt-in so that the step kernel's launch time in bench.py / profiles/ is that of the kernel alone.
   // (policy: lmc_problem.moments_overlap / moments_bg_workgroups, LMC_MOMENTS_OVERLAP / LMC_MOMENTS_BG_WGS as defaults; fixed at creation)
-  const bool want_overlap = s->pol_overlap ? s->pol_overlap > 0 : (long long)s->C * s->prob.H * s->prob.W <= (1LL << 25);
+  // Round 3: on by default at every size -- what bench.py's `value` measures -- and off while the launches are being event-timed
+  // (lmc_sampler_enable_timing: the roofline leg wants the step kernel alone).
+  const bool want_overlap = !s->timing && (s->pol_overlap ? s->pol_overlap > 0 : true);
   const int bg_wgs = s->pol_bg_wgs >= 0 ? s->pol_bg_wgs : ((long long)s->C * s->prob.H * s->prob.W <= (1LL << 25) ? 128 : 256);   // 0: the full-speed kernel
   bool overlap = want_overlap && s->moments && n_iters > 1;
   if (overlap && !s->side) {
@@ -1414,7 +1423,22 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     else HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_step, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&s->ev_mom[i], hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&s->ev_pair[i], hipEventDisableTiming));
   }
+  // the same for launches that advance two iterations: both iterates are reduced on the side stream under the NEXT pair launch
+  auto pair_wait = [&](int p) -> int {        // the pair launch about to be enqueued writes where launch n - 2's reductions read
+    if (s->pair_pending[p]) { HIP_TRY(hipStreamWaitEvent(st, s->ev_pair[p], 0)); s->pair_pending[p] = false; }
+    return LMC_OK;
+  };
+  auto pair_reduce = [&](int p, const float* mid, const float* outp) -> int {   // after the pair launch: its kept iterates, on the side stream
+    HIP_TRY(hipEventRecord(s->ev_step, st));
+    HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
+    if (mid) HIP_TRY(lmc::launch_moments_bg(mid, s->C, s->prob.H, s->prob.W, s->s1, s->s2, bg_wgs, s->side));
+    if (outp) HIP_TRY(lmc::launch_moments_bg(outp, s->C, s->prob.H, s->prob.W, s->s1, s->s2, bg_wgs, s->side));
+    HIP_TRY(hipEventRecord(s->ev_pair[p], s->side));
+    s->pair_pending[p] = true;
+    return LMC_OK;
+  };
   // graph replay: whole blocks of kGraphIters iterations whose every iteration is kept by the moment accumulators (or none is)
   const bool graph_ok = !s->timing && (!overlap || s->pol_graph) && !noise_dev && s->noise_mode != LMC_NOISE_INJECTED && s->prob.ncvx_kind != LMC_NCVX_ME_TV &&
                         !s->tvwarm[0] && !s->rtmp && !s->rt_tv.kc && (!s->moments || s->thin == 1) && graph_wanted(s);
@@ -1443,7 +1467,7 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     // Two MYULA iterations per launch (lmc_step_rows_pair.hip) where that kernel covers the configuration and the launch is large enough for its
     // long bands: x_{k+2} goes to a third array (neighbouring bands re-read x_k), x_{k+1} is stored only when the moment accumulators keep it.
     // lmc_problem.iterations_per_launch / LMC_ROWS_PAIR: 0 = never, 2 = wherever covered (tests), default = where it pays (n_chains * H >= 2^17).
-    if (pair_mode && n_iters - k >= 2 && !noise_dev && !overlap && !graph_ok && !s->tvwarm[0] && !s->rtmp && s->prob.ncvx_kind == LMC_NCVX_NONE &&
+    if (pair_mode && n_iters - k >= 2 && !noise_dev && !graph_ok && !s->tvwarm[0] && !s->rtmp && s->prob.ncvx_kind == LMC_NCVX_NONE &&
         (variant_of(s->prob) == 0 || variant_of(s->prob) == 6) && (pair_mode == 2 || (long long)s->C * s->prob.H >= (1 << 17))) {
       lmc::StepArgs A = s->base;
       A.x_in = s->x[s->cur];
@@ -1456,14 +1480,33 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
         }
         auto kept = [&](int64_t it) { return s->moments && it >= s->burn_in && (it - s->burn_in) % s->thin == 0; };
         const bool keep_mid = kept(s->iteration), keep_out = kept(s->iteration + 1);
+        const int pp = (int)(s->pair_n & 1);
+        float* mid = keep_mid ? s->x[s->cur ^ 1] : nullptr;
+        if (overlap && (keep_mid || keep_out)) {     // the reductions of this launch run under the next one: the iterate in between gets an array of its own
+          if (keep_mid) {
+            if (!s->xmid[pp]) HIP_TRY(hipMalloc(&s->xmid[pp], sizeof(float) * per_iter));
+            mid = s->xmid[pp];
+          }
+          int rc = pair_wait(pp);
+          if (rc) return rc;
+        }
+        for (int i = 0; i < 2; ++i)                 // (single launches of this call that ran before: their side-stream reductions read x[0] / x[1])
+          if (s->mom_pending[i]) { HIP_TRY(hipStreamWaitEvent(st, s->ev_mom[i], 0)); s->mom_pending[i] = false; }
         A.x_out = s->xspare;
         if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches], st));
-        HIP_TRY(lmc::launch_step_rows_pair(A, keep_mid ? s->x[s->cur ^ 1] : nullptr, st));
+        HIP_TRY(lmc::launch_step_rows_pair(A, mid, st));
         if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches + 1], st));
         s->kernel_name = "myula_step_rows_pair_kernel";
         s->plain_done = true;
-        if (keep_mid) { HIP_TRY(lmc::launch_moments(s->x[s->cur ^ 1], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
-        if (keep_out) { HIP_TRY(lmc::launch_moments(s->xspare, s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
+        if (overlap && (keep_mid || keep_out)) {
+          int rc = pair_reduce(pp, keep_mid ? mid : nullptr, keep_out ? s->xspare : nullptr);
+          if (rc) return rc;
+          s->count += (uint64_t)s->C * ((keep_mid ? 1 : 0) + (keep_out ? 1 : 0));
+        } else {
+          if (keep_mid) { HIP_TRY(lmc::launch_moments(mid, s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
+          if (keep_out) { HIP_TRY(lmc::launch_moments(s->xspare, s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
+        }
+        ++s->pair_n;
         std::swap(s->x[s->cur], s->xspare);        // x[cur] = x_{k+2}; the array that held x_k is the spare now
         for (int i = 0; i < 2; ++i)                // captured graphs hold the old pointers
           if (s->gexec[i]) { (void)hipGraphExecDestroy(s->gexec[i]); s->gexec[i] = nullptr; }
@@ -1476,7 +1519,7 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     // Two iterations per launch on the register-block kernel (Haar prior, stencil-free data term: BASELINE config 5): the update never leaves a
     // thread's 8 x 8 block, so the second iteration runs on the block while it is on chip; x_{k+1} is written (in place, over x_k) only when the
     // moment accumulators keep it.  LMC_BLOCK_PAIR=0 turns it off.  Same arithmetic, same noise: bit-identical to two launches.
-    if (blockpair_on && n_iters - k >= 2 && !noise_dev && !overlap && !graph_ok && !s->tvwarm[0] && !s->rtmp && s->prob.ncvx_kind == LMC_NCVX_NONE &&
+    if (blockpair_on && n_iters - k >= 2 && !noise_dev && !graph_ok && !s->tvwarm[0] && !s->rtmp && s->prob.ncvx_kind == LMC_NCVX_NONE &&
         (variant_of(s->prob) == 0 || variant_of(s->prob) == 5)) {
       lmc::StepArgs A = s->base;
       A.x_in = s->x[s->cur];
@@ -1491,15 +1534,35 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
         const int nf = four ? 4 : 2;
         const bool keep_mid = !four && kept(s->iteration), keep_out = kept(s->iteration + nf - 1);
         A.fused_iters = nf;
-        A.x_mid = keep_mid ? s->x[s->cur] : nullptr;
+        A.x_mid = keep_mid ? s->x[s->cur] : nullptr;          // in place over x_k (the update is block-local) ...
+        const int pp = (int)(s->pair_n & 1);
+        const bool side_red = overlap && (keep_mid || keep_out);
+        if (side_red) {                                       // ... unless its reduction runs under the next launch, which writes x_{k+3} there
+          if (keep_mid) {
+            if (!s->xmid[pp]) HIP_TRY(hipMalloc(&s->xmid[pp], sizeof(float) * per_iter));
+            A.x_mid = s->xmid[pp];
+          }
+          int rc = pair_wait(pp);
+          if (rc) return rc;
+        }
+        for (int i = 0; i < 2; ++i)
+          if (s->mom_pending[i]) { HIP_TRY(hipStreamWaitEvent(st, s->ev_mom[i], 0)); s->mom_pending[i] = false; }
         if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches], st));
         HIP_TRY(lmc::launch_step_block(A, st));
         if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches + 1], st));
         s->kernel_name = four ? "myula_step_block_kernel(4 iterations)" : "myula_step_block_kernel(2 iterations)";
         s->plain_done = true;
-        if (keep_mid) { HIP_TRY(lmc::launch_moments(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
-        s->cur ^= 1;
-        if (keep_out) { HIP_TRY(lmc::launch_moments(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
+        if (side_red) {
+          int rc = pair_reduce(pp, keep_mid ? A.x_mid : nullptr, keep_out ? s->x[s->cur ^ 1] : nullptr);
+          if (rc) return rc;
+          s->count += (uint64_t)s->C * ((keep_mid ? 1 : 0) + (keep_out ? 1 : 0));
+          s->cur ^= 1;
+        } else {
+          if (keep_mid) { HIP_TRY(lmc::launch_moments(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
+          s->cur ^= 1;
+          if (keep_out) { HIP_TRY(lmc::launch_moments(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st)); s->count += (uint64_t)s->C; }
+        }
+        ++s->pair_n;
         s->iteration += nf;
         ++s->last_launches;
         k += nf - 1;
@@ -1518,6 +1581,8 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
       A.extra = s->extra;
       A.extra_coef = -s->prob.ncvx_lambda / s->prob.ncvx_gamma;
     }
+    for (int i = 0; i < 2; ++i)          // reductions of earlier pair launches of this call may still read the array this step writes
+      if (s->pair_pending[i]) { HIP_TRY(hipStreamWaitEvent(st, s->ev_pair[i], 0)); s->pair_pending[i] = false; }
     if (s->mom_pending[s->cur ^ 1]) {   // this step overwrites x[cur ^ 1]: the reduction that still reads it must be done
       HIP_TRY(hipStreamWaitEvent(st, s->ev_mom[s->cur ^ 1], 0));
       s->mom_pending[s->cur ^ 1] = false;
@@ -1572,8 +1637,10 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     ++s->iteration;
     ++s->last_launches;
   }
-  for (int i = 0; i < 2; ++i)             // everything this call enqueued is ordered before whatever the caller enqueues next
+  for (int i = 0; i < 2; ++i) {           // everything this call enqueued is ordered before whatever the caller enqueues next
     if (s->mom_pending[i]) { HIP_TRY(hipStreamWaitEvent(st, s->ev_mom[i], 0)); s->mom_pending[i] = false; }
+    if (s->pair_pending[i]) { HIP_TRY(hipStreamWaitEvent(st, s->ev_pair[i], 0)); s->pair_pending[i] = false; }
+  }
   s->timed = s->timing;
   return LMC_OK;
 }

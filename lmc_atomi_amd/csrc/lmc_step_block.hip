@@ -93,7 +93,10 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
   const float ts = P.t * P.sigma_f;
   // MC-TV window: wr[k][m] = x(row, block column m - 1), rows r-1, r, r+1 in slots (r-1)%3 ... ; addresses are clamped into the image,
   // the has_* flags of mc_tv_grad make the clamped values irrelevant
-  float wr[MC ? 3 : 1][MC ? 10 : 1];
+  // (round 3) v = A x / max(|A x|, gamma) is formed once per pixel, row by row -- (vx, vy) of block row r from window rows r and r + 1, for the block
+  // columns -1 .. 7 -- and A^T v at (r, j) = -((vx[r][j] - vx[r-1][j]) + (vy[r][j] - vy[r][j-1])): the same values, operation for operation, as
+  // mc_tv_grad recomputes per pixel for its three weights, with a third of the square roots and reciprocals and one window row less in registers.
+  float wr[MC ? 2 : 1][MC ? 10 : 1], vxp[MC ? 8 : 1], vxc[MC ? 9 : 1], vyc[MC ? 9 : 1];
   const int gi0 = by * 8, gj0 = bx * 8;
   const float* __restrict__ ximg = P.x_in + (size_t)chain * img;
   auto load_wrow = [&](float (&d)[MC ? 10 : 1], int rr) {      // rr: block-local row -1 .. 8
@@ -111,7 +114,35 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
       d[9] = row[min(gj0 + 8, W - 1)];
     }
   };
-  if constexpr (MC) { load_wrow(wr[0], -1); load_wrow(wr[1], 0); }
+  // (vx, vy) of block row rr (-1 .. 7) from window rows `cu` (row rr) and `dn` (row rr + 1): columns m - 1 for m = 0 .. 8
+  auto v_row = [&](const float (&cu)[MC ? 10 : 1], const float (&dn)[MC ? 10 : 1], int rr) {
+    if constexpr (MC) {
+      const int gi = gi0 + rr;
+      const bool rowin = gi >= 0, down = gi + 1 < H, an = P.ncvx_gamma < 0.f;
+      const float gth = fabsf(P.ncvx_gamma);
+#pragma unroll
+      for (int m = 0; m < 9; ++m) {
+        const int gj = gj0 + m - 1;
+        const bool colin = gj >= 0;
+        const float dx = (rowin && colin && down) ? dn[m] - cu[m] : 0.f;
+        const float dy = (rowin && colin && gj + 1 < W) ? cu[m + 1] - cu[m] : 0.f;
+        if (an) {
+          vxc[m] = __builtin_amdgcn_rcpf(fmaxf(fabsf(dx), gth)) * dx;
+          vyc[m] = __builtin_amdgcn_rcpf(fmaxf(fabsf(dy), gth)) * dy;
+        } else {
+          const float w = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy)), gth));
+          vxc[m] = w * dx;
+          vyc[m] = w * dy;
+        }
+      }
+    }
+  };
+  if constexpr (MC) {
+    load_wrow(wr[0], -1); load_wrow(wr[1], 0);
+    v_row(wr[0], wr[1], -1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vxp[j] = vxc[j + 1];
+  }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     float nz[8][4];
@@ -150,7 +181,10 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
 #pragma unroll
         for (int j = 0; j < 8; ++j) xi[j] = P.noise_mode == LMC_NOISE_PHILOX ? nz[j][k] : 0.f;
       }
-      if constexpr (MC) load_wrow(wr[(r + 2) % 3], r + 1);
+      if constexpr (MC) {        // window rows r (slot (r + 1) & 1) and r + 1 (loaded into the slot row r - 1 has left)
+        load_wrow(wr[r & 1], r + 1);
+        v_row(wr[(r + 1) & 1], wr[r & 1], r);
+      }
       float o[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -164,12 +198,11 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
         else if (PRIOR == LMC_PRIOR_L1) px = soft_thr_b(x, P.prior_p0);
         else if (PRIOR == LMC_PRIOR_EPROX) px = eprox(P.eprox_kind, x, EproxParams{P.prior_p0, P.prior_p1});   // closed forms of prox.py
         o[j] = fmaf(P.b, px, fmaf(P.s, xi[j], fmaf(P.a, x, -ts * g)));
-        if constexpr (MC) {
-          const float (&up)[10] = wr[r % 3], (&cu)[10] = wr[(r + 1) % 3], (&dn)[10] = wr[(r + 2) % 3];
-          const int gi = gi0 + r, gj = gj0 + j;
-          o[j] = fmaf(P.t * P.ncvx_lambda, mc_tv_grad(up[j + 1], up[j + 2], cu[j], cu[j + 1], cu[j + 2], dn[j], dn[j + 1], gi > 0, gi + 1 < H,
-                                                      gj > 0, gj + 1 < W, P.ncvx_gamma), o[j]);
-        }
+        if constexpr (MC) o[j] = fmaf(P.t * P.ncvx_lambda, -((vxc[j + 1] - vxp[j]) + (vyc[j + 1] - vyc[j])), o[j]);
+      }
+      if constexpr (MC) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vxp[j] = vxc[j + 1];
       }
       if (last_it) {
         *reinterpret_cast<float4*>(dst + (size_t)r * W) = make_float4(o[0], o[1], o[2], o[3]);
