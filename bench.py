@@ -37,6 +37,18 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.
 BYTES_PER_PIXEL_STEP = 8       # algorithmic: one fp32 read of x_k + one fp32 write of x_{k+1}
 
 
+def kernel_source_hash():
+    """sha256 (12 hex digits) over the HIP sources of the library: profiles/r03_counters.json entries carry the hash of the sources they were
+    measured on, and the bench line quotes `roofline.traffic` / `roofline.valu` from them only while the sources are still the same."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "lmc_atomi_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def synth_problem(H, W, sigma, seed=0, blur="box", blur_k=5):
     """Piecewise-constant + ramp ground truth in [0,255] from default_rng(1234); y = H u + N(0, sigma^2)
     with noise from default_rng(seed) (mirrors prox_lmc_deconv.py:53-59).  Host-side setup, not timed."""
@@ -283,15 +295,17 @@ def main():
             want["tv_warm"] = True
         if args.tv_lagged:
             want["tv_lagged"] = True
-        for prof in ("r02_counters.json", "r01_traffic.json"):       # the newest committed counters of this kernel on this workload
-            try:
-                for ent in json.load(open(os.path.join(ROOT, "profiles", prof)))["entries"]:
-                    if ent["workload"] == want and ent["kernel"] == smp.kernel_name and traffic is None:
-                        traffic = ent["traffic_bytes_per_launch"]
-                        if "valu" in ent:
-                            valu = dict(ent["valu"], source=ent.get("source"))
-            except Exception:
-                pass
+        counters_from = None
+        src_hash = kernel_source_hash()
+        try:             # the newest committed counters of this kernel on this workload -- only while the kernel sources are the ones they were taken on
+            for ent in json.load(open(os.path.join(ROOT, "profiles", "r03_counters.json")))["entries"]:
+                if ent["workload"] == want and ent["kernel"] == smp.kernel_name and traffic is None and ent.get("source_hash") == src_hash:
+                    traffic = ent["traffic_bytes_per_launch"]
+                    counters_from = {"file": ent.get("source"), "source_hash": ent.get("source_hash"), "commit": ent.get("commit")}
+                    if "valu" in ent:
+                        valu = dict(ent["valu"], source=ent.get("source"))
+        except Exception:
+            pass
         peak_measured = None
         if not args.no_hbm_probe:
             import ctypes
@@ -340,6 +354,8 @@ def main():
                 "frac_of_measured": (achieved / peak_measured) if peak_measured else None,
                 "peak_measured_how": "lmc_hbm_copy_probe: 1 GiB read + 1 GiB written, float4 per lane, best of 10 launch shapes x 3 passes, this process",
                 "traffic": traffic,
+                "counters_from": counters_from,      # null (and traffic / valu null) when the HIP sources have changed since the committed PMC passes
+                "kernel_source_hash": src_hash,
                 "launch_ms": per_launch_ms,
                 "launches": launches,
                 "algorithmic_bytes_per_launch": int(BYTES_PER_PIXEL_STEP * H * W * C * its_per_launch),

@@ -22,7 +22,7 @@ namespace lmc {
 #define LMC_ROWS_PF 4
 #endif
 #ifndef LMC_ROWS_PF4
-#define LMC_ROWS_PF4 3
+#define LMC_ROWS_PF4 4
 #endif
 #ifndef LMC_ROWS_PF7
 #define LMC_ROWS_PF7 2
@@ -36,7 +36,7 @@ struct RowsGeom {
   static constexpr int HW = (KT - 1) / 2;         // taps are centred: window c-HW .. c+HW
   static constexpr int LAG = KT - 1;              // output row = input row - LAG
   // x rows fetched ahead; PF + LAG <= 8 keeps row o's slot intact.  The depth is what the register file allows without spilling (scratch sizes are
-  // fenced by tests/test_kernel_resources.py).  At 7 taps and 8 pixels per lane three rings of 7-8 rows x 8 pixels leave little: x rows 2 steps ahead
+  // fenced by tests/test_kernel_resources.py): 4 at 5 taps (8 or 4 pixels per lane).  At 7 taps and 8 pixels per lane three rings of 7-8 rows x 8 pixels leave little: x rows 2 steps ahead
   // and the observation row requested in the step that uses it (measured at 512 x 512 x 1024, 7 x 7 box + l2 prior: 0.600 ms per launch; x 1 ahead /
   // y 1 ahead 0.629; x 1 / y 0: 0.665; round 2's 2 / 1 with 23 spilled VGPRs: 0.647), 1 ahead for the 6 x 6 box (window 0..5), which still spilled at 2
   static constexpr int PFW = (PXL == 8 && KT == 7) ? LMC_ROWS_PF7 : (PXL == 4 ? LMC_ROWS_PF4 : LMC_ROWS_PF);

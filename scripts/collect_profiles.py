@@ -1,9 +1,15 @@
 #!/usr/bin/env python3
 """Copy the summaries of gpurun_out/prof_<round>_*/ (scripts/profile.sh) into profiles/ and assemble profiles/<round>_counters.json, the
 file bench.py reads the per-launch HBM traffic and the VALU-busy fraction of the step kernel from.  usage: collect_profiles.py r02"""
-import json, os, re, shutil, sys
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+import json, os, re, shutil, subprocess, sys
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash      # the hash bench.py compares before it quotes these counters
+SRC_HASH = kernel_source_hash()
+COMMIT = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+DIRTY = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "lmc_atomi_amd/csrc"], capture_output=True, text=True).stdout.strip())
+T512 = {"H": 512, "W": 512, "C": 1024, "data": "blur", "tv_iters": 10, "ncvx": "none"}
 WORK = {   # tag -> (bench.py workload key, sampler kernel name)
     "pipe": ({"H": 512, "W": 512, "C": 1024, "prior": "tv", "data": "blur", "tv_iters": 10, "ncvx": "none"}, "myula_step_pipe_kernel"),
     "rows": ({"H": 512, "W": 512, "C": 1024, "prior": "l2", "data": "blur", "tv_iters": 10, "ncvx": "none"}, "myula_step_rows_kernel"),
@@ -16,6 +22,12 @@ WORK = {   # tag -> (bench.py workload key, sampler kernel name)
     "warm3": ({"H": 512, "W": 512, "C": 1024, "prior": "tv", "data": "blur", "tv_iters": 3, "ncvx": "none", "tv_warm": True}, "myula_step_pipe_kernel(warm)"),
     "wide877tv": ({"H": 667, "W": 877, "C": 512, "prior": "tv", "data": "blur", "tv_iters": 10, "ncvx": "none"}, "myula_step_pipe_kernel"),
     "wide877l2": ({"H": 667, "W": 877, "C": 512, "prior": "l2", "data": "blur", "tv_iters": 10, "ncvx": "none"}, "myula_step_rows_kernel"),
+    # round 3
+    "pipert": (dict(T512, prior="tv", tv_rtol=1e-4), "myula_step_pipe_kernel(per-chain exit)"),
+    "pipe7": (dict(T512, prior="tv", blur_k=7), "myula_step_pipe_kernel"),
+    "pipemc": (dict(T512, prior="tv", ncvx="mc"), "myula_step_pipe_kernel"),
+    "rows7": (dict(T512, prior="l2", blur_k=7), "myula_step_rows_kernel"),
+    "c5": ({"H": 512, "W": 512, "C": 512, "prior": "haar", "data": "mask", "tv_iters": 10, "ncvx": "mc"}, "myula_step_block_kernel"),
 }
 entries = []
 for d in sorted(os.listdir(os.path.join(ROOT, "gpurun_out"))):
@@ -35,6 +47,7 @@ for d in sorted(os.listdir(os.path.join(ROOT, "gpurun_out"))):
     for k, ent in cj["kernels"].items():
         if base in k and "traffic_bytes_per_launch" in ent:
             e = {"kernel": kname, "kernel_instantiation": k, "workload": work, "source": f"profiles/{rnd}_{tag}_rocprofv3_summary.txt",
+                 "source_hash": SRC_HASH, "commit": COMMIT + ("+dirty" if DIRTY else ""),
                  "FETCH_SIZE_KiB": ent["counters"]["FETCH_SIZE"], "WRITE_SIZE_KiB": ent["counters"]["WRITE_SIZE"],
                  "traffic_bytes_per_launch": ent["traffic_bytes_per_launch"],
                  "algorithmic_bytes_per_launch": 8 * work["H"] * work["W"] * work["C"] * (2 if ("pair" in kname or "2 iterations" in kname) else 1),   # a pair launch = two iterations
