@@ -9,6 +9,9 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
+# the step kernel ALONE, as bench.py's event-timed region measures it (roofline.launch_ms): moment reductions in line, not on the side stream
+# (bench.py's `value` is measured with them on the side stream: the default)
+export LMC_MOMENTS_OVERLAP=${LMC_MOMENTS_OVERLAP:-0}
 args="--steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-hbm-probe $*"
 targs="--steps 60 --warmup 10 --repeats 1 --no-cpu-baseline --no-hbm-probe $*"   # long enough for clocks to settle: the average must agree with bench.py
 cd $root
