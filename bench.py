@@ -340,6 +340,8 @@ def main():
                             + ("no moments" if args.no_moments else f"posterior moments every {args.thin} it"),
                 "image": [H, W], "chains_per_gpu": C, "chains_total": C * world, "tv_iters": args.tv_iters,
                 "sampler": "MYULA (algs.py:477-587)" if args.alg == "myula" else "MYMALA (Metropolis-adjusted MYULA, generalises prox_lmc.py:134-158)" if args.alg == "mymala" else f"ULPDA (algs.py:295-474), implicit step by CG: at most {args.cg_iters} iterations, stops at |r| <= 1e-6 |b| for every chain (the reference solver's rule, algs.py:250)", "parallelism": f"chains sharded x{world}",
+                "moment_reductions": ("none" if args.no_moments else "every kept iterate, on a side stream under the next step kernel (lmc_sampler_step default; "
+                                      "roofline.launch_ms is measured in a separate event-timed region with the reductions in line, i.e. the kernel alone)"),
                 "iterations_per_s": args.steps / elapsed,
                 "collective": collective,
             },
@@ -382,6 +384,35 @@ def main():
             ps, rr = smp.tv_exit_stats("ncvx")
             pc = np.bincount(ps.cpu().numpy(), minlength=(args.ncvx_iters or args.tv_iters) + 1)
             out["config"]["ncvx_exit"] = {"passes_histogram_last_iteration": pc.tolist(), "reruns_after_round_1_2_3_4": rr}
+        headline = (args.prior == "tv" and args.alg == "myula" and args.ncvx == "none" and args.data == "blur" and args.tv_iters == 10 and not args.tv_warm
+                    and not args.tv_lagged and H == 512 and W == 512)
+        if headline and not args.tv_rtol:
+            # what binds the K = 10 kernel is the vector ALU, not HBM: the bound of ITS instruction stream (ISA counts x measured issue times)
+            out["roofline"]["valu_bound_ms"] = {
+                "perfectly_balanced": 1.34 * C / 1024.0, "whole_waves_on_simds": 1.52 * C / 1024.0,
+                "how": "per tick and role, VALU instructions of the ISA (scripts/isa_loops.py) x issue time per class (scripts/ubench/inst_rate.hip): 2593 ns of SIMD time per "
+                       "tick and CU = 648 per SIMD if it could be split evenly; with whole waves on SIMDs the busiest SIMD (T1 + T5) carries 710 ns; x 536 ticks x 4 "
+                       "rounds of 256 workgroups"}
+        if headline and not args.tv_rtol and world == 1 and os.environ.get("LMC_BENCH_AS_CONFIGURED", "1") != "0":
+            # beside the headline (fixed K = 10 passes): the same chain AS THE REFERENCE IS CONFIGURED -- pyproximal.TV's default rtol = 1e-4, which
+            # prox_lmc_deconv.py:122 leaves in force; the exit is decided on the device, chain by chain.  60 warm-up iterations: the pass counts
+            # fall 10 -> 4 over the first ~30 iterations from x0 = 0, every change a re-run of the chains concerned.
+            smp.close()
+            pg2 = la.TV((H, W), sigma=tau_reg, niter=10, rtol=1e-4)
+            smp2 = la.MYULASampler(pf, pg2, (H, W), n_chains=C, tau=tau, gamma=gamma, seed=0, chain_offset=rank * C, moments=not args.no_moments)
+            smp2.set_state(np.zeros((H, W), dtype=np.float32))
+            smp2.step(60)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            smp2.step(args.steps)
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t0
+            ps, rr = smp2.tv_exit_stats("prior")
+            out["config"]["reference_as_configured"] = {
+                "what": "TV(niter=10, rtol=1e-4): every chain leaves its prox in the pass upstream's loop leaves it in; same kernels, per-chain live stage counts",
+                "ms_per_step": el2 / args.steps * 1e3, "value": C * args.steps / el2, "unit": "chain-it/s", "steps": args.steps, "warmup": 60,
+                "passes_histogram_last_iteration": np.bincount(ps.cpu().numpy(), minlength=11).tolist(), "reruns_after_round_1_2_3_4": rr}
+            smp2.close()
         if args.alg == "mymala":
             out["config"]["acceptance_rate_mean"] = float(smp.acceptance_rate().mean())
             out["config"]["tau_scale"] = args.tau_scale

@@ -31,8 +31,12 @@ def synthetic_image(ny=512, nx=512, seed=1234):
 
 
 def prox_lmc_deconv(gamma_mc=15., gamma_me=15., sigma=0.75, tau=0.3, N=1000, niter_l2=50, niter_tv=10, image=None,
-                    alg='ULPDA', seed=0, n_chains=None, burn_in=0, thin=1, models=None, verbose=True, diagnostics=None):
+                    alg='ULPDA', seed=0, n_chains=None, burn_in=0, thin=1, models=None, verbose=True, diagnostics=None, rtol=1e-4):
     """Posterior means of the nine models M1..M9 (prox_lmc_deconv.py:447-703) by ULPDA or MYULA on the GPU.
+
+    ``rtol``: the early exit of the TV proxes AS THE REFERENCE IS CONFIGURED -- ``pyproximal.TV(dims, sigma, niter=niter_tv)`` leaves upstream's default
+    ``rtol = 1e-4`` in force (:122) and ``algs.L2_ncvx_tv`` has it as its own default (algs.py:130,169).  Decided on the device, chain by chain (DESIGN
+    3.0r); ``rtol=0``: every prox runs all its passes.  (MYMALA: the TV prior keeps the fixed count -- its Metropolis test needs one proposal map.)
 
     ``n_chains=None`` runs the reference's single chain (every iterate kept on the host, mean over iterates,
     ``:474``); ``n_chains=C`` runs C chains per model and averages over chains and kept iterations.
@@ -59,7 +63,7 @@ def prox_lmc_deconv(gamma_mc=15., gamma_me=15., sigma=0.75, tau=0.3, N=1000, nit
             return L2_ncvx_tv(dims=(ny, nx), Op=H[k], Op2=Gop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau, gamma=gamma_mc,
                               isotropic=True, niter=niter_l2, warm=True)
         return L2_ncvx_tv(dims=(ny, nx), Op=H[k], b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau, gamma=gamma_me,
-                          isotropic=True, niter=niter_l2, warm=True)
+                          isotropic=True, niter=niter_l2, rtol=rtol, warm=True)
 
     order = [("M1", 5, "tv"), ("M2", 5, "mc"), ("M3", 5, "me"), ("M4", 6, "tv"), ("M5", 6, "mc"), ("M6", 6, "me"),
              ("M7", 7, "tv"), ("M8", 7, "mc"), ("M9", 7, "me")]
@@ -74,7 +78,7 @@ def prox_lmc_deconv(gamma_mc=15., gamma_me=15., sigma=0.75, tau=0.3, N=1000, nit
                                                niter=N, seed=seed, n_chains=n_chains, burn_in=burn_in, thin=thin,
                                                **({"diagnostics": diagnostics} if (diagnostics and n_chains) else {}))
         elif alg == 'MYULA':                                        # :465-473
-            res = MoreauYosidaUnadjustedLangevin(f, TV(dims=(ny, nx), sigma=tau, niter=niter_tv), tau=tau_myula,
+            res = MoreauYosidaUnadjustedLangevin(f, TV(dims=(ny, nx), sigma=tau, niter=niter_tv, rtol=rtol), tau=tau_myula,
                                                  gamma=gamma_myula, x0=x0, niter=N, seed=seed, n_chains=n_chains,
                                                  burn_in=burn_in, thin=thin,
                                                  **({"diagnostics": diagnostics} if (diagnostics and n_chains) else {}))
@@ -114,6 +118,7 @@ def main(argv=None):
     ap.add_argument("--N", type=int, default=1000)
     ap.add_argument("--niter_l2", type=int, default=50)
     ap.add_argument("--niter_tv", type=int, default=10)
+    ap.add_argument("--rtol", type=float, default=1e-4, help="early exit of the TV proxes (1e-4: the reference as configured; 0: always all passes)")
     ap.add_argument("--alg", default="ULPDA", choices=["ULPDA", "MYULA", "MYMALA"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--n_chains", type=int, default=None)
@@ -127,7 +132,7 @@ def main(argv=None):
     a = ap.parse_args(argv)
     img = np.load(a.image) if a.image else synthetic_image(a.size, a.size)
     res = prox_lmc_deconv(a.gamma_mc, a.gamma_me, a.sigma, a.tau, a.N, a.niter_l2, a.niter_tv, img, a.alg, a.seed, a.n_chains,
-                          a.burn_in, a.thin, a.models.split(",") if a.models else None, diagnostics=a.diagnostics)
+                          a.burn_in, a.thin, a.models.split(",") if a.models else None, diagnostics=a.diagnostics, rtol=a.rtol)
     if a.out:
         flat = {}
         for k, v in res.items():

@@ -41,6 +41,7 @@ CASES = [
     ("config3_tv", (512, 512), 1024, "blur", "tv"),        # BASELINE config 3: deblur + isotropic TV, 1024 chains
     ("config2_l2", (256, 256), 128, "blur", "l2"),         # BASELINE config 2: deblur + l2 prior, 128 chains
     ("config5_haar", (512, 512), 512, "mask", "haar"),     # BASELINE config 5 shape: inpainting mask + Haar-l1 (chains of one GPU)
+    ("config5_as_specified", (512, 512), 512, "mask_mc", "haar"),   # + the L2_ncvx_tv Moreau-difference (MC-TV) term, lamda = 0.3, gamma = 15
 ]
 
 
@@ -60,6 +61,10 @@ def test_fullsize_properties(la, name, shape, C, data, prior):
         mask = (np.random.default_rng(7).uniform(size=shape) < 0.5).astype(np.float64)
         y = mask * (img + rng.normal(0, sigma, shape))
         pf = la.L2(Op=la.Diagonal(mask, dims=shape), b=y, sigma=1 / sigma ** 2, dims=shape)
+        if data == "mask_mc":        # non-log-concave: f(x) = sigma/2 ||M x - y||^2 - lamda * env_gamma(l1)(grad x)   (algs.py:270-291)
+            pf = la.L2_ncvx_tv(dims=shape, Op=la.Diagonal(mask, dims=shape), Op2=la.Gradient(shape), b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=15.0,
+                               isotropic=True)
+            of = O.L2NcvxTV(dims=shape, Op=O.Diagonal(mask), Op2=O.Gradient(shape), b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=15.0, isotropic=True)
     if prior == "tv":
         pg, op = la.TV(shape, sigma=tau_reg, niter=10), {"kind": "tv", "sigma": tau_reg, "niter": 10, "t": gamma}
     elif prior == "l2":
@@ -83,7 +88,10 @@ def test_fullsize_properties(la, name, shape, C, data, prior):
     x = np.zeros((1,) + shape)
     for k in range(nit):
         xi = O.philox_normals(seed, k, np.array([base + c]), *shape).astype(np.float64)
-        x = O.myula_step(x, y, h, off, 1 / sigma ** 2, tau, gamma, op, xi, mask=mask)
+        if data == "mask_mc":        # the update of algs.py:569 assembled from the checker's class gradient and the Haar prox
+            x = ((1 - tau / gamma) * x - tau * of.grad(x.ravel()).reshape(x.shape) + (tau / gamma) * O.haar_l1_prox(x, gamma * tau_reg) + np.sqrt(2 * tau) * xi)
+        else:
+            x = O.myula_step(x, y, h, off, 1 / sigma ** 2, tau, gamma, op, xi, mask=mask)
     assert rel(xb[c].cpu().numpy(), x[0]) < 5e-6 * nit, (name, rel(xb[c].cpu().numpy(), x[0]))
     # (3) moments = sums over chains and kept iterations; with x0 = 0 and nit steps, recompute the last term from the states
     s1, s2, n = big.moments()
