@@ -638,7 +638,6 @@ int tv_prox_rt(lmc::StepArgs A, RtState& rt, float rtol, float* st0, float* st1,
   A.rt_kc = rt.kc; A.rt_start = rt.start; A.rt_obj = rt.obj; A.rt_stride = rt.stride;
   HIP_TRY(lmc::launch_tv_rt_begin(A.C, rt.pred, rt.kc, rt.start, rt.obj, rt.stride, niter, st));
   for (int round = 0; round < kRtRounds; ++round) {
-    if (round > 0) A.mom_src = nullptr;          // the moment-reduction wave rides on the first round only (every chain's workgroup runs in it)
     hipError_t e = lmc::launch_step_pipe_rt(A, st, st0, st1);
     if (e == hipErrorInvalidConfiguration) return fail(LMC_E_UNSUPPORTED, "the device-side early exit of the TV prox does not cover this configuration");
     HIP_TRY(e);
@@ -805,7 +804,6 @@ struct lmc_sampler {
   int pol_bg_wgs = -1;       // workgroups of the background reduction, -1 by size
   int pol_graph = 0;
   int pol_side_lowprio = 1;
-  int pol_fuse_moments = 1;  // 1: the K = 10 pipe kernels reduce the previous iterate in their ninth wave (LMC_MOMENTS_FUSE=0: off)
   bool pol_ulpda_dual_rhs = false;   // ULPDA, opt-in experiment (LMC_ULPDA_DUAL_RHS=1 at creation): dual update fused with the next right-hand side
   Problem prob;
   int C = 0;
@@ -824,7 +822,6 @@ struct lmc_sampler {
   hipEvent_t ev_pair[2] = {nullptr, nullptr};
   bool pair_pending[2] = {false, false};
   uint64_t pair_n = 0;
-  bool mom_owed = false;      // the moments of x[cur] (a kept iterate) are still to be accumulated: the next pipe launch's ninth wave does it, or a pass at the end of the call
   int cur = 0;
   double* s1 = nullptr;
   double* s2 = nullptr;
@@ -1172,7 +1169,6 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
     s->pol_bg_wgs = q.moments_bg_wgs > 0 ? q.moments_bg_wgs : env_int("LMC_MOMENTS_BG_WGS", -1);
     s->pol_graph = q.graph_replay ? 1 : (env_int("LMC_GRAPH", 0) == 1);
     s->pol_side_lowprio = env_int("LMC_MOMENTS_SIDE_PRIO", 1) != 0;
-    s->pol_fuse_moments = (s->pol_overlap < 0) ? 0 : (env_int("LMC_MOMENTS_FUSE", 1) != 0);      // moments_overlap = -1 / LMC_MOMENTS_OVERLAP=0: every reduction in line, in its own pass
   }
   if (e == hipSuccess && s->prob.tv_warm) {
     lmc::StepArgs probe = s->base;
@@ -1591,16 +1587,6 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
       HIP_TRY(hipStreamWaitEvent(st, s->ev_mom[s->cur ^ 1], 0));
       s->mom_pending[s->cur ^ 1] = false;
     }
-    // Moments inside the step kernel (round 3): where the launch is a K = 10 pipe kernel, its ninth wave reduces the state the previous launch wrote --
-    // this launch's input -- while the update runs; the iterate of the call's last iteration is reduced by a pass of its own at the end.
-    const bool rt_fused_path = s->rt_tv.kc && A.prior_kind == LMC_PRIOR_TV_ISO && A.tv.niter <= 10;
-    const bool fuse_mom = s->moments && s->pol_fuse_moments && !s->timing && !s->tvwarm[0] && !s->rtmp && (variant_of(s->prob) == 0 || variant_of(s->prob) == 7) &&
-                          A.prior_kind == LMC_PRIOR_TV_ISO && lmc::pipe_fuses_moments(A, rt_fused_path) && (rt_fused_path || !s->rt_tv.kc);
-    if (s->mom_owed) {
-      if (fuse_mom) { A.mom_src = A.x_in; A.mom_s1 = s->s1; A.mom_s2 = s->s2; }
-      else HIP_TRY(lmc::launch_moments(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st));
-      s->mom_owed = false;
-    }
     if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches], st));
     const char* kname = nullptr;
     hipError_t e;
@@ -1635,9 +1621,7 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches + 1], st));
     s->cur ^= 1;
     if (s->moments && s->iteration >= s->burn_in && (s->iteration - s->burn_in) % s->thin == 0) {
-      if (fuse_mom && k + 1 < n_iters) {  // the next launch's ninth wave reduces x[cur]
-        s->mom_owed = true;
-      } else if (overlap && k + 1 < n_iters) {   // reduce x[cur] on the side stream while the next step kernel runs
+      if (overlap && k + 1 < n_iters) {   // reduce x[cur] on the side stream while the next step kernel runs
         HIP_TRY(hipEventRecord(s->ev_step, st));
         HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
         HIP_TRY(lmc::launch_moments_bg(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, bg_wgs, s->side));
@@ -1652,10 +1636,6 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     }
     ++s->iteration;
     ++s->last_launches;
-  }
-  if (s->mom_owed) {                      // (cannot happen: the last iteration of a call never defers; kept for the pair / graph paths that `continue`)
-    HIP_TRY(lmc::launch_moments(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, st));
-    s->mom_owed = false;
   }
   for (int i = 0; i < 2; ++i) {           // everything this call enqueued is ordered before whatever the caller enqueues next
     if (s->mom_pending[i]) { HIP_TRY(hipStreamWaitEvent(st, s->ev_mom[i], 0)); s->mom_pending[i] = false; }

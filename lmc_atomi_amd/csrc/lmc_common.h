@@ -85,11 +85,6 @@ struct StepArgs {
   // rt_kc[c] < 0), or when this link lies before rt_start[c] (its result of an earlier round is still valid).  By-products: the primal objective 0.5 ||x - sol_j||^2 + gamma TV(sol_j) of every iterate formed -- stage g adds that of
   // its input iterate to rt_obj[c][g - 1], the combine wave that of the iterate it returns to rt_obj[c][rt_kc[c]] (unless that is rt_total,
   // the iterate returned untested).  fp64 sums; rt_obj must be zero where this launch adds.
-  // pipe kernel, K = 10 single-launch instantiations: posterior moments of `mom_src` ([C][H][W]: the state the previous launch wrote -- normally x_in)
-  // are accumulated into mom_s1 / mom_s2 ([H][W] fp64) by the workgroups' ninth wave while the update runs (NULL: not asked for)
-  const float* mom_src;
-  double* mom_s1;
-  double* mom_s2;
   const int* rt_kc;
   const int* rt_start;     // [C] (chained prox) first link chain c needs in this round: the links before it return at once -- their work of an earlier round stands
   double* rt_obj;

@@ -73,10 +73,6 @@ int centred_blur_taps(const BlurTaps& T, float* uc, float* vc);
 bool pipe_supported(const StepArgs& a);                  // one launch covers it (10 dual iterations)
 int pipe_links(const StepArgs& a);                       // launches needed (20 .. 60 iterations: chained through HBM state), 0 = not covered
 hipError_t launch_step_pipe(StepArgs a, hipStream_t st, float* state0 = nullptr, float* state1 = nullptr);
-// true when launch_step_pipe / launch_step_pipe_rt would run `a` on a kernel that carries the moment-reduction wave (StepArgs::mom_src): one launch of 10
-// dual iterations (RT: up to 10), rows 16-byte aligned with the last column a lane's last pixel, one column strip, and a workload of at most two
-// (slice, chain) items per tick and workgroup
-bool pipe_fuses_moments(const StepArgs& a, bool rt);
 // warm-started TV prox: a.tv_in / a.tv_out = [C][2][H][W] projected dual of the previous / this MYULA iteration
 bool pipe_warm_supported(const StepArgs& a);
 hipError_t launch_step_pipe_warm(StepArgs a, hipStream_t st);

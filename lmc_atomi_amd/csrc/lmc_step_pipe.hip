@@ -44,16 +44,6 @@ int pipe_links(const StepArgs& a) {
 
 bool pipe_supported(const StepArgs& a) { return pipe_links(a) == 1; }
 
-bool pipe_fuses_moments(const StepArgs& a, bool rt) {
-  if (a.prior_kind != LMC_PRIOR_TV_ISO || a.tv_in || a.tv_out || a.tv_state_only || a.tv_warm) return false;
-  if (rt ? (a.tv.niter < 1 || a.tv.niter > 10) : a.tv.niter != 10) return false;
-  if (!pipe_geometry_ok(a) || a.W > 512 || (a.W & (a.W > 256 ? 7 : 3))) return false;
-  // (slice, chain) items per workgroup and tick: ceil(ceil(H W / 256) / C) * C / (H + D + 3 rounded)
-  const long long nsl = ((long long)a.H * a.W + 255) / 256, per_wg = (nsl + a.C - 1) / a.C * a.C;
-  const int t_end = (a.H + 22 + 3) & ~3;
-  return (per_wg + t_end - 1) / t_end <= (a.W > 256 ? 2 : 1);       // what the kernel's prefetch ring holds (8 / 4 pixels per lane)
-}
-
 // warm-started prox: the projected dual (p, q) of the previous MYULA iteration comes in through a.tv_in and the new one leaves through
 // a.tv_out ([C][2][H][W] each, never NULL), a.tv.niter in {1, 2, 3} dual iterations per MYULA iteration
 bool pipe_warm_supported(const StepArgs& a) {

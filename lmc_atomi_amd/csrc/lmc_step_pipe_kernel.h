@@ -266,15 +266,11 @@ __host__ __device__ constexpr int pipe_halo(int K, int KT, int PXL) {
 // them pass (rr, ss) through unchanged -- a delay line with the live stages' timing, so the combine wave forms x - gamma div(rr^kc, ss^kc) -- and every
 // iterate formed leaves its primal objective behind.  In a chained launch the link a chain leaves in does its combine; the links before it only
 // advance the dual state, the ones after it return at once.
-// Moments inside the step kernel (round 3): in the K = 10 single-launch kernels the combine wave also reduces the posterior moments of the INPUT state
-// while the update runs -- the iterate the previous launch wrote, i.e. the one a separate reduction pass would have read (StepArgs::mom_src, [C][H][W];
-// NULL: nothing).  Workgroup b owns the 256-pixel slices b, b + C, ... of the image and sums them over all C chains: one or two (slice, chain) float4 items
-// per tick, requested four ticks ahead, fp64 accumulators, one pair of atomics per pixel when a slice is complete -- 1 GB read per launch at the headline
-// size, spread over the launch, ~50 ns of fp64 work per tick on the workgroup's least loaded SIMD (T2 + C: DESIGN 7).  (A ninth wave of its own was the first
-// form: three waves on one SIMD cap the kernel at 168 VGPRs -- 128 to 184 spilled.)
-template <int K, bool CHAIN, bool WARM, bool AL>
-constexpr bool pipe_has_mom_wave() { return K == 10 && !CHAIN && !WARM && AL; }
-
+// (Round 3, measured and removed again -- git history, commit 49bc3f1 and the three builds after it: the posterior moments of the INPUT state reduced inside this
+// kernel, workgroup b summing the 256-pixel slices b, b + C, ... over all chains, two 1 KB reads per tick.  As a ninth wave: three waves on one SIMD cap the kernel
+// at 168 VGPRs, 128-184 spilled.  In the combine wave: its conditional stores make the compiler wait for every load in flight each tick, 4.05 ms per iteration.  In the
+// Philox wave, sums in registers, loads 4 / 8 ticks ahead: 2.41 / 2.32 ms against 1.92 with the reduction on a side stream -- and with the loads alone, no arithmetic,
+// still 2.61 against 2.05 with the arithmetic alone: the CU's outstanding-miss capacity is what the scattered reads take from the L wave's row prefetches.)
 template <int K, int PXL, int KT, bool CHAIN = false, bool WARM = false, bool AL = true, bool RT = false>
 __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM ? LMC_WARM_MIN_WAVES : 1) : 2) void myula_step_pipe_kernel(const StepArgs A) {
   static_assert(!WARM || CHAIN, "the warm dual uses the state hand-over of the chained launches");
@@ -762,74 +758,10 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
         gload_raw<PXL>(exq[u], A.extra + (size_t)chain * img + (size_t)min(max(r, 0), H - 1) * W, c0, W, al);
       }
     }
-    // ---- posterior moments of the input state (see the comment above the kernel) ----
-    const float* __restrict__ msrc = pipe_has_mom_wave<K, CHAIN, WARM, AL>() ? A.mom_src : nullptr;
-    const int nC = (int)gridDim.x;
-    const int nsl = (int)((img + 255) / 256);
-    const int n_my = (msrc && gridDim.y == 1 && (int)blockIdx.x < nsl) ? (nsl - (int)blockIdx.x + nC - 1) / nC : 0;
-    const long long n_items = (long long)n_my * nC;                                  // (slice, chain) pairs of this workgroup, slice-major
-    const int qq = (int)((n_items + T_end - 1) / T_end);                              // per tick: 1 or 2 (the host asks pipe_fuses_moments() first)
-    constexpr int QM = PXL / 4;                                                       // items per tick the prefetch ring holds: 2 at 8 pixels per lane (W > 256), 1 at 4
-    const bool mom_on = n_items > 0 && qq <= QM;
-    double ma[4] = {0.0, 0.0, 0.0, 0.0}, mb[4] = {0.0, 0.0, 0.0, 0.0};
-    float4 pre[4][QM];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int v = 0; v < QM; ++v) pre[u][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto item_ptr = [&](long long i) -> const float4* {        // item i: slice ordinal i / nC, chain i % nC; lanes past the image read its last group
-      const int k = (int)(i / nC), c = (int)(i - (long long)k * nC);
-      const size_t p = ((size_t)blockIdx.x + (size_t)k * nC) * 256 + (size_t)lane * 4;
-      return reinterpret_cast<const float4*>(msrc + (size_t)c * img + (p < img ? p : img - 4));
-    };
-    if (mom_on) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < QM; ++v) {
-          const long long i = (long long)u * qq + v;
-          if (v < qq && i < n_items) pre[u][v] = *item_ptr(i);
-        }
-    }
     auto tick = [&](auto uu, const int t) __attribute__((always_inline)) {
       constexpr int U = decltype(uu)::value, P = U & 1;
       constexpr int NI = ((U - D) % 4 + 4) % 4;        // == o & 3  (t = 4m + U)
       const int o = t - D;
-      if constexpr (pipe_has_mom_wave<K, CHAIN, WARM, AL>()) {
-      if (mom_on) {
-#pragma unroll
-        for (int v = 0; v < QM; ++v) {
-          const long long i = (long long)t * qq + v;
-          if (v < qq && i < n_items) {
-            const float4 x4 = pre[U][v];
-            const double d0 = x4.x, d1 = x4.y, d2 = x4.z, d3 = x4.w;
-            ma[0] += d0; ma[1] += d1; ma[2] += d2; ma[3] += d3;
-            mb[0] = fma(d0, d0, mb[0]); mb[1] = fma(d1, d1, mb[1]); mb[2] = fma(d2, d2, mb[2]); mb[3] = fma(d3, d3, mb[3]);
-            const int k = (int)(i / nC), c = (int)(i - (long long)k * nC);
-            if (c == nC - 1) {          // the slice is complete: lane-contiguous atomics after a transpose inside the wave (as moments4_kernel)
-              const size_t pw = ((size_t)blockIdx.x + (size_t)k * nC) * 256;
-              const int sel = lane & 3;
-#pragma unroll
-              for (int kk = 0; kk < 4; ++kk) {
-                const int srcl = 16 * kk + (lane >> 2);
-                double va = 0.0, vb = 0.0;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                  const double ta = __shfl(ma[m], srcl, 64), tb = __shfl(mb[m], srcl, 64);
-                  if (sel == m) { va = ta; vb = tb; }
-                }
-                const size_t q = pw + (size_t)kk * 64 + lane;
-                if (q < img) { unsafeAtomicAdd(&A.mom_s1[q], va); unsafeAtomicAdd(&A.mom_s2[q], vb); }
-              }
-#pragma unroll
-              for (int m = 0; m < 4; ++m) { ma[m] = 0.0; mb[m] = 0.0; }
-            }
-          }
-          const long long ip = (long long)(t + 4) * qq + v;
-          if (v < qq && ip < n_items) pre[U][v] = *item_ptr(ip);
-        }
-      }
-      }
       if (state_only) { PIPE_TICK_SYNC(); return; }     // this link only advances the dual state (of this chain)
       if (A.extra) {
         const int r3 = o + 3;
@@ -988,7 +920,6 @@ static hipError_t pipe_launch_one(const StepArgs& a, hipStream_t st) {
   }
   const int BWk = 64 * PXL, U = BWk - 2 * pipe_halo(K, KT, PXL);
   const int nstrips = a.W <= BWk ? 1 : (a.W + U - 1) / U;       // wider than one wave: column strips with recomputed halos
-  if (a.mom_src && (!pipe_has_mom_wave<K, CHAIN, WARM, AL>() || nstrips != 1)) return hipErrorInvalidConfiguration;   // callers ask pipe_fuses_moments() first
   hipLaunchKernelGGL(kern, dim3(a.C, nstrips), dim3(64 * ((K + 1) / 2 + 3)), lb, st, a);
   return hipGetLastError();
 }

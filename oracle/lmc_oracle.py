@@ -442,8 +442,10 @@ def tv_prox_fgp(x, gamma, niter, step=0.125, betas=None, rtol=0.0, momentum="unl
         return x - gamma*div(rr,ss)
 
     ``rtol > 0`` adds the reference's per-image early exit on the relative change of the
-    primal objective; the device path always runs the fixed ``niter`` (rtol = 0), so a
-    batched launch does the same work for every chain (documented deviation).
+    primal objective (upstream's default 1e-4 is what ``prox_lmc_deconv.py:122`` and
+    ``algs.py:169`` leave in force); the device follows it chain by chain when asked to
+    (``TV(rtol=...)`` / ``L2_ncvx_tv(rtol=...)``) and runs the fixed ``niter``
+    at ``rtol = 0``.
 
     NAMED RISK (cannot be settled in this image: pyproximal is neither vendored nor installable).  Upstream forms ``sol`` at the
     TOP of each loop pass, tests the exit, updates the dual, and returns the ``sol`` of the pass it leaves in.  Whether ``niter``
@@ -452,7 +454,7 @@ def tv_prox_fgp(x, gamma, niter, step=0.125, betas=None, rtol=0.0, momentum="unl
     version.  This restatement returns the iterate after ``niter`` updates; the other reading is ``niter - 1`` here, and the
     device runs either (``lmc_problem.tv_lagged_output``).  Likewise upstream's default ``rtol = 1e-4`` (which the reference's
     call ``TV(dims, sigma, niter=niter_tv)`` does not override) stops a typical MYULA iterate's prox after about 3 passes
-    (tests/test_oracle_operators.py::test_tv_rtol_exit_statistics); the device and the goldens use ``rtol = 0``.
+    (tests/test_oracle_operators.py::test_tv_rtol_exit_statistics); tests/golden/algs.npz uses ``rtol = 0``, algs_rtol.npz both.
 
     ``dual0 = (p, q)`` starts from that projected dual instead of zero with the momentum restarted (the build's warm-dual
     variant; NOT the reference's algorithm); ``return_dual`` also returns the final ``(p, q)``.
