@@ -72,8 +72,12 @@ typedef enum lmc_ncvx_kind {
   LMC_NCVX_MC_TV = 1,   /* minimax-concave TV (Moreau envelope of l1 composed with the gradient), isotropic */
   LMC_NCVX_ME_TV = 2,   /* Moreau envelope of isotropic TV itself (Op2 = None): grad env = (x - prox_{gamma TV}(x))/gamma,
                          * prox by ncvx_niter FGP iterations (niter_l2 = 50 at prox_lmc_deconv.py:111; algs.py:169,282) */
-  LMC_NCVX_MC_TV_ANISO = 3   /* the anisotropic MC-TV branches (isotropic = False, Op2 = gradient; algs.py:218-219, 278-279): the Moreau
+  LMC_NCVX_MC_TV_ANISO = 3,  /* the anisotropic MC-TV branches (isotropic = False, Op2 = gradient; algs.py:218-219, 278-279): the Moreau
                               * envelope of l1 on every component of the gradient: grad = A^T clip(A x / gamma, -1, 1) */
+  LMC_NCVX_ME_TV_ANISO = 4   /* (ABI 3) the anisotropic ME-TV branch (isotropic = False, Op2 = None; algs.py:170): the Moreau envelope of the 1-D TV of
+                              * the FLATTENED image (row-major, differences across row ends included), inner prox by ncvx_niter 1-D FGP iterations with
+                              * the early exit ncvx_rtol.  Plain coverage (one pass over the images per dual iteration; with ncvx_rtol > 0 the host reads
+                              * a counter after every pass): no model of the reference's driver uses it. */
 } lmc_ncvx_kind;
 
 typedef enum lmc_noise_mode {

@@ -17,7 +17,7 @@ ABI_VERSION = 3
 DATA_NONE, DATA_IDENTITY, DATA_BLUR, DATA_MASK = 0, 1, 2, 3
 PRIOR_NONE, PRIOR_L2, PRIOR_L1, PRIOR_TV_ISO, PRIOR_TV_ANISO, PRIOR_HAAR_L1, PRIOR_EPROX = 0, 1, 2, 3, 4, 5, 6
 NOISE_PHILOX, NOISE_INJECTED, NOISE_NONE = 0, 1, 2
-NCVX_NONE, NCVX_MC_TV, NCVX_ME_TV, NCVX_MC_TV_ANISO = 0, 1, 2, 3
+NCVX_NONE, NCVX_MC_TV, NCVX_ME_TV, NCVX_MC_TV_ANISO, NCVX_ME_TV_ANISO = 0, 1, 2, 3, 4
 MAX_BLUR = 9
 MAX_TV_ITERS = 64
 (EPROX_LAPLACE, EPROX_UNCENTERED_LAPLACE, EPROX_GAUSSIAN, EPROX_GEN_GAUSSIAN_4_3, EPROX_GEN_GAUSSIAN_3_2,

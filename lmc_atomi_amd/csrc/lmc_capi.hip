@@ -72,6 +72,7 @@ struct Problem {
   int ncvx_kind = 0;
   float ncvx_lambda = 0.f, ncvx_gamma = 1.f;
   int ncvx_niter = 0;
+  int ncvx_aniso = 0;       // ME-TV: the 1-D TV of the flattened image (LMC_NCVX_ME_TV_ANISO)
   int tv_warm = 0;
   float tv_rtol = 0.f;      // > 0: pyproximal.TV's per-image early exit (device path tv_prox_rt, or the pass-by-pass path tv_prox_rtol)
   float ncvx_rtol = 0.f;    // > 0: the same for the inner prox of the ME-TV term (device path only)
@@ -250,17 +251,20 @@ int load_problem(const lmc_problem* p, Problem& q) {
   }
   if (p->prior_kind != LMC_PRIOR_NONE && p->prior_kind != LMC_PRIOR_EPROX && !(p->prior_sigma >= 0.f)) return fail(LMC_E_INVALID, "prior_sigma must be >= 0");
   if (p->ncvx_kind != LMC_NCVX_NONE) {
-    if (p->ncvx_kind != LMC_NCVX_MC_TV && p->ncvx_kind != LMC_NCVX_ME_TV && p->ncvx_kind != LMC_NCVX_MC_TV_ANISO)
+    if (p->ncvx_kind != LMC_NCVX_MC_TV && p->ncvx_kind != LMC_NCVX_ME_TV && p->ncvx_kind != LMC_NCVX_MC_TV_ANISO && p->ncvx_kind != LMC_NCVX_ME_TV_ANISO)
       return fail(LMC_E_INVALID, "unknown ncvx_kind %d", p->ncvx_kind);
     if (!(p->ncvx_gamma > 0.f)) return fail(LMC_E_INVALID, "ncvx_gamma must be > 0");
-    if (p->ncvx_kind == LMC_NCVX_ME_TV && (p->ncvx_niter < 1 || p->ncvx_niter > lmc::kMaxTvIters))
+    const bool me = p->ncvx_kind == LMC_NCVX_ME_TV || p->ncvx_kind == LMC_NCVX_ME_TV_ANISO;
+    if (me && (p->ncvx_niter < 1 || p->ncvx_niter > lmc::kMaxTvIters))
       return fail(LMC_E_INVALID, "ncvx_niter %d outside 1..%d", p->ncvx_niter, lmc::kMaxTvIters);
     q.ncvx_kind = p->ncvx_kind; q.ncvx_lambda = p->ncvx_lambda; q.ncvx_gamma = p->ncvx_gamma;
+    // anisotropic ME-TV: inside the library the ME-TV kind with the 1-D inner prox (every code path that adds the term's gradient serves both)
+    if (p->ncvx_kind == LMC_NCVX_ME_TV_ANISO) { q.ncvx_kind = LMC_NCVX_ME_TV; q.ncvx_aniso = 1; }
     // anisotropic MC-TV: inside the library the same kind with a NEGATIVE gamma -- mc_tv_grad (lmc_device.h) and the energy kernels take
     // the sign as "component-wise weights 1 / max(|d|, gamma)" instead of the pixel norm; every MC-TV code path serves both
     if (p->ncvx_kind == LMC_NCVX_MC_TV_ANISO) { q.ncvx_kind = LMC_NCVX_MC_TV; q.ncvx_gamma = -p->ncvx_gamma; }
-    q.ncvx_niter = p->ncvx_niter - ((p->ncvx_kind == LMC_NCVX_ME_TV && p->tv_lagged_output) ? 1 : 0);
-    if (p->ncvx_kind == LMC_NCVX_ME_TV) {
+    q.ncvx_niter = p->ncvx_niter - ((me && p->tv_lagged_output) ? 1 : 0);
+    if (me) {
       if (!(p->ncvx_rtol >= 0.f) || p->ncvx_rtol >= 1.f) return fail(LMC_E_INVALID, "ncvx_rtol must be in [0, 1)");
       q.ncvx_rtol = p->ncvx_rtol;
     }
@@ -621,7 +625,7 @@ int cg_solve_fused(const Problem& q, float ts, float* u, const float* rhs, float
 
 bool needs_tv_state(const Problem& q) {
   return (q.prior_kind == LMC_PRIOR_TV_ISO && (q.tv_niter > 12 || (q.tv_rtol > 0.f && q.tv_niter > 10))) ||
-         (q.ncvx_kind == LMC_NCVX_ME_TV && (q.ncvx_niter > 12 || (q.ncvx_rtol > 0.f && q.ncvx_niter > 10)));
+         (q.ncvx_kind == LMC_NCVX_ME_TV && (q.ncvx_aniso || q.ncvx_niter > 12 || (q.ncvx_rtol > 0.f && q.ncvx_niter > 10)));
 }
 
 // The TV prox inside A (a complete StepArgs: prox only, or the whole fused update when A.tv.niter <= 10) with upstream's per-image early exit,
@@ -649,6 +653,42 @@ int tv_prox_rt(lmc::StepArgs A, RtState& rt, float rtol, float* st0, float* st1,
 int tv_prox_rtol(const Problem& q, float pt, const float* x, float* sol, float* tmp, double* obj, int* flag, int64_t n, float* st0, float* st1,
                  hipStream_t st);
 
+// out <- prox_{gam TV_1D}(x) of the n flattened images (N = H W entries each) by `niter` 1-D FGP iterations (lmc_ops.hip: tv1d_*), with upstream's early
+// exit when rtol > 0 (pass by pass: the host reads the number of images still iterating after every pass).  buf: 4 n N floats (dual, dual, projected dual,
+// iterate); obj: 2 n doubles; flag: n + 1 ints.
+int tv1d_prox(const float* x, float* out, int64_t n, size_t N, float gam, int niter, float rtol, float* buf, double* obj, int* flag, hipStream_t st) {
+  const size_t tot = (size_t)n * N;
+  float *rr[2] = {buf, buf + tot}, *p = buf + 2 * tot, *tmp = buf + 3 * tot;
+  float betas[lmc::kMaxTvIters];
+  default_betas(betas, niter);
+  const float cstep = 0.25f / gam;
+  double *prev = obj, *cur = obj + n;
+  int* n_active = flag + n;
+  HIP_TRY(hipMemsetAsync(buf, 0, sizeof(float) * 3 * tot, st));
+  HIP_TRY(hipMemsetAsync(obj, 0, sizeof(double) * 2 * n, st));
+  HIP_TRY(hipMemsetAsync(flag, 0xFF, sizeof(int) * n, st));
+  for (int j = 0; j <= niter; ++j) {
+    const float* r_now = rr[j & 1];
+    if (rtol > 0.f || j == niter) HIP_TRY(lmc::launch_tv1d_sol(x, r_now, tmp, n, N, gam, flag, st));
+    if (j == niter) {                                                        // out of passes: the rest take sol_niter untested
+      HIP_TRY(lmc::launch_tv_rtol_select(tmp, out, flag, -1, n, N, st));
+      break;
+    }
+    if (rtol > 0.f) {
+      HIP_TRY(lmc::launch_tv1d_objective(x, tmp, n, N, gam, flag, cur, st));
+      HIP_TRY(hipMemsetAsync(n_active, 0, sizeof(int), st));
+      HIP_TRY(lmc::launch_tv_rtol_decide(n, prev, cur, flag, j, (double)rtol, n_active, st));
+      if (j > 0) HIP_TRY(lmc::launch_tv_rtol_select(tmp, out, flag, j, n, N, st));
+      int active = 0;
+      HIP_TRY(hipMemcpyAsync(&active, n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (active == 0) break;
+    }
+    HIP_TRY(lmc::launch_tv1d_iter(x, r_now, p, rr[(j & 1) ^ 1], n, N, gam, cstep, betas[j], flag, st));
+  }
+  return LMC_OK;
+}
+
 // extra <- prox_{gamma TV}(x) with ncvx_niter dual iterations (the inner prox of the ME-TV term, algs.py:169,282)
 int me_tv_prox(const Problem& q, const float* x, float* extra, int64_t n_img, float* state0, float* state1, hipStream_t st, RtState* rt = nullptr) {
   lmc::StepArgs A;
@@ -667,6 +707,12 @@ int me_tv_prox(const Problem& q, const float* x, float* extra, int64_t n_img, fl
   if (q.ncvx_niter == 0) {     // lagged output of a 1-iteration prox: x itself
     HIP_TRY(hipMemcpyAsync(extra, x, sizeof(float) * (size_t)n_img * q.H * q.W, hipMemcpyDeviceToDevice, st));
     return LMC_OK;
+  }
+  if (q.ncvx_aniso) {          // algs.py:170: the 1-D TV of the flattened image
+    if (!state0) return fail(LMC_E_STATE, "anisotropic ME-TV: work buffers are missing");
+    Scratch& sc = g_scratch;
+    HIP_TRY(sc.need_dbl(3 * (size_t)n_img + 2));
+    return tv1d_prox(x, extra, n_img, (size_t)q.H * q.W, q.ncvx_gamma, q.ncvx_niter, q.ncvx_rtol, state0, sc.dbl, reinterpret_cast<int*>(sc.dbl + 2 * n_img), st);
   }
   if (q.ncvx_rtol > 0.f) {     // the class's own rtol (algs.py:130,169): per-chain early exit
     if (rt && q.tv_exit_path == 0 && lmc::pipe_rt_supported(A)) return tv_prox_rt(A, *rt, q.ncvx_rtol, state0, state1, st);     // on the device
@@ -995,6 +1041,10 @@ static int me_tv_energy(const Problem& q, const float* x, int64_t n_img, double*
   lmc::EnergyArgs E;
   std::memset(&E, 0, sizeof E);
   E.H = q.H; E.W = q.W; E.data_kind = LMC_DATA_NONE; E.prior_kind = LMC_PRIOR_TV_ISO; E.prior_sigma = 1.f;
+  if (q.ncvx_aniso) {                                                                    // TV_1D(prox) of the flattened image
+    HIP_TRY(hipMemsetAsync(dbl, 0, sizeof(double) * n_img, st));
+    HIP_TRY(lmc::launch_tv1d_objective(extra, extra, n_img, (size_t)q.H * q.W, 1.f, nullptr, dbl, st));
+  } else
   HIP_TRY(lmc::launch_energies(extra, n_img, E, nullptr, dbl, st));                       // TV(prox)
   HIP_TRY(lmc::launch_sqdiff(x, extra, n_img, (size_t)q.H * q.W, dbl + n_img, st));      // ||x - prox||^2
   HIP_TRY(lmc::launch_axpy_env(f_out, dbl, dbl + n_img, n_img, q.ncvx_lambda, q.ncvx_gamma, st));

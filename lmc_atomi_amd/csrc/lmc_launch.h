@@ -41,6 +41,11 @@ hipError_t launch_bump_u32(uint32_t* p, uint32_t by, hipStream_t st);
 hipError_t launch_tv_objective(const float* x, const float* sol, int64_t n, int H, int W, float gam, const int* flag, double* obj, hipStream_t st);
 hipError_t launch_tv_rtol_decide(int64_t n, double* prev, double* cur, int* flag, int pass, double rtol, int* n_active, hipStream_t st);
 hipError_t launch_tv_rtol_select(const float* tmp, float* sol, const int* flag, int pass, int64_t n, size_t img, hipStream_t st);
+// 1-D TV over the flattened image (inner prox of the anisotropic ME-TV term, algs.py:170): one dual iteration / the primal iterate / its objective
+hipError_t launch_tv1d_sol(const float* x, const float* rr, float* out, int64_t n, size_t N, float gam, const int* flag, hipStream_t st);
+hipError_t launch_tv1d_iter(const float* x, const float* rr_in, float* p, float* rr_out, int64_t n, size_t N, float gam, float cstep, float beta, const int* flag,
+                            hipStream_t st);
+hipError_t launch_tv1d_objective(const float* x, const float* sol, int64_t n, size_t N, float gam, const int* flag, double* obj, hipStream_t st);
 // the early exit without leaving the device (speculate / verify / re-run; lmc_ops.hip, lmc_capi.hip: tv_prox_rt)
 hipError_t launch_tv_rt_begin(int64_t n, const int* pred, int* kc, int* start, double* obj, int stride, int niter, hipStream_t st);
 hipError_t launch_tv_rt_decide(int64_t n, int* kc, int* start, int* pred, double* obj, int stride, int niter, double rtol, int round,

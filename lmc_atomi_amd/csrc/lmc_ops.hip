@@ -731,6 +731,74 @@ hipError_t launch_tv_rtol_select(const float* tmp, float* sol, const int* flag, 
   return hipGetLastError();
 }
 
+// ---- 1-D TV over the flattened image: the inner prox of the ANISOTROPIC ME-TV term of algs.L2_ncvx_tv (algs.py:170: pyproximal.TV((prod(dims),), 1., niter,
+// rtol)) ----  No model of the reference's driver uses it (prox_lmc_deconv.py:106-113 are the isotropic ones), so this is plain coverage: one pass over the
+// images per dual iteration, dual and projected dual ping-ponged through memory, the same pass-by-pass early exit as tv_prox_rtol (lmc_capi.hip: tv1d_prox).
+// One dual component r: sol = x - gam div(rr), div(r)[i] = r[i] - r[i-1] with the last entry of r taken as zero; r = rr - c (sol[i+1] - sol[i]) (0 at the
+// end), p' = r / max(1, |r|), rr' = p' + beta (p' - p).  Images with flag[c] >= 0 (left already) are skipped.
+__device__ __forceinline__ float tv1d_sol_at(const float* __restrict__ x, const float* __restrict__ rr, size_t i, size_t N, float gam) {
+  const float ri = i + 1 < N ? rr[i] : 0.f, rm = i > 0 ? rr[i - 1] : 0.f;
+  return x[i] - gam * (ri - rm);
+}
+__global__ __launch_bounds__(256) void tv1d_sol_kernel(const float* __restrict__ x, const float* __restrict__ rr, float* __restrict__ out, size_t N, float gam,
+                                                       const int* __restrict__ flag) {
+  const size_t c = blockIdx.y;
+  if (flag && flag[c] >= 0) return;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x)
+    out[c * N + i] = tv1d_sol_at(x + c * N, rr + c * N, i, N, gam);
+}
+__global__ __launch_bounds__(256) void tv1d_iter_kernel(const float* __restrict__ x, const float* __restrict__ rr_in, float* __restrict__ p, float* __restrict__ rr_out,
+                                                        size_t N, float gam, float cstep, float beta, const int* __restrict__ flag) {
+  const size_t c = blockIdx.y;
+  if (flag && flag[c] >= 0) return;
+  const float* xc = x + c * N;
+  const float* rc = rr_in + c * N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = i + 1 < N ? tv1d_sol_at(xc, rc, i + 1, N, gam) - tv1d_sol_at(xc, rc, i, N, gam) : 0.f;
+    const float r = rc[i] - cstep * d;
+    const float pn = r / fmaxf(1.f, fabsf(r));
+    rr_out[c * N + i] = pn + beta * (pn - p[c * N + i]);
+    p[c * N + i] = pn;
+  }
+}
+// obj[c] += 1/2 ||x_c - sol_c||^2 + gam TV_1D(sol_c)   (gam = 1 and x = sol: the 1-D TV value alone)
+__global__ __launch_bounds__(256) void tv1d_objective_kernel(const float* __restrict__ x, const float* __restrict__ sol, size_t N, float gam, const int* __restrict__ flag,
+                                                             double* __restrict__ obj) {
+  __shared__ double scratch[4];
+  const size_t c = blockIdx.y;
+  if (flag && flag[c] >= 0) return;
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = sol[c * N + i];
+    const float d = x[c * N + i] - v;
+    const float dn = i + 1 < N ? sol[c * N + i + 1] - v : 0.f;
+    acc += 0.5 * (double)d * (double)d + (double)gam * (double)fabsf(dn);
+  }
+  const double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) unsafeAtomicAdd(&obj[c], t);
+}
+static dim3 tv1d_grid(int64_t n, size_t N) {
+  size_t gx = (N + 255) / 256;
+  if (gx > 256) gx = 256;
+  return dim3((unsigned)gx, (unsigned)n);
+}
+hipError_t launch_tv1d_sol(const float* x, const float* rr, float* out, int64_t n, size_t N, float gam, const int* flag, hipStream_t st) {
+  if (n > 65535) return hipErrorInvalidConfiguration;
+  hipLaunchKernelGGL(tv1d_sol_kernel, tv1d_grid(n, N), dim3(256), 0, st, x, rr, out, N, gam, flag);
+  return hipGetLastError();
+}
+hipError_t launch_tv1d_iter(const float* x, const float* rr_in, float* p, float* rr_out, int64_t n, size_t N, float gam, float cstep, float beta, const int* flag,
+                            hipStream_t st) {
+  if (n > 65535) return hipErrorInvalidConfiguration;
+  hipLaunchKernelGGL(tv1d_iter_kernel, tv1d_grid(n, N), dim3(256), 0, st, x, rr_in, p, rr_out, N, gam, cstep, beta, flag);
+  return hipGetLastError();
+}
+hipError_t launch_tv1d_objective(const float* x, const float* sol, int64_t n, size_t N, float gam, const int* flag, double* obj, hipStream_t st) {
+  if (n > 65535) return hipErrorInvalidConfiguration;
+  hipLaunchKernelGGL(tv1d_objective_kernel, tv1d_grid(n, N), dim3(256), 0, st, x, sol, N, gam, flag, obj);
+  return hipGetLastError();
+}
+
 // ---- the same early exit without leaving the device (lmc_capi.hip: tv_prox_rt): speculate, verify, re-run -------------------------------------
 // A chain's prox runs with a PREDICTED number of dual updates k (the pass it left in at the previous call: the objective is a sum over the
 // whole image and moves little from one MYULA iterate to the next), fused in the RT instantiations of the pipe kernel, which leave the primal

@@ -468,8 +468,9 @@ class L2_ncvx_tv(ProxOperator):
     * ME-TV (``Op2 = None``): value and gradient ``sigma Op^T(Op x - b) - lamda (x - prox_{gamma TV}(x))/gamma`` (:282), the inner
       TV prox with ``niter`` (= niter_l2 = 50) dual iterations chained exactly through HBM-resident dual state in chunks of 8.
     ``prox`` (:201-267) is built for both (ME-TV pre-step :221-223).  Round 2: the anisotropic MC-TV branches too (``isotropic=False``
-    with ``Op2 = Gradient``: :218-219, :278-279 -- the weight of a difference is 1 / max(|that difference|, gamma)).  Not built:
-    anisotropic ME-TV (a 1-D TV over the flattened image, :170) -- it raises.
+    with ``Op2 = Gradient``: :218-219, :278-279 -- the weight of a difference is 1 / max(|that difference|, gamma)).  Round 3: anisotropic
+    ME-TV (``isotropic=False``, ``Op2 = None``: a 1-D TV over the flattened image, :170) as plain coverage -- one pass over the images per
+    dual iteration of its inner prox, not fused (no model of the reference's driver uses it).
     """
 
     def __init__(self, dims, Op=None, Op2=None, b=None, q=None, sigma=1., alpha=1., lamda=1., gamma=.5, qgrad=True,
@@ -478,9 +479,6 @@ class L2_ncvx_tv(ProxOperator):
         from .operators import Gradient
         if q is not None:
             raise NotImplementedError("q (linear term) has no device functor")
-        if not isotropic and Op2 is None:
-            raise NotImplementedError("anisotropic ME-TV (algs.py:170: a 1-D TV over the flattened image) is not built; the anisotropic MC-TV "
-                                      "branches (Op2 = Gradient) and both isotropic ones are")
         if Op2 is not None and not isinstance(Op2, Gradient):
             raise NotImplementedError("Op2 must be a Gradient (MC-TV) or None (ME-TV)")
         if not isinstance(Op, (Convolve2D, Diagonal)) or b is None:
@@ -503,7 +501,10 @@ class L2_ncvx_tv(ProxOperator):
             base = {"data_kind": _capi.DATA_MASK, "sigma_f": self.sigma, "y": self.b, "mask": self.Op.d}
         else:
             base = {"data_kind": _capi.DATA_BLUR, "sigma_f": self.sigma, "y": self.b, "h": self.Op.h, "offset": self.Op.offset}
-        kind = _capi.NCVX_ME_TV if self.Op2 is None else (_capi.NCVX_MC_TV if self.isotropic else _capi.NCVX_MC_TV_ANISO)
+        if self.Op2 is None:       # ME-TV: isotropic (2-D TV, algs.py:169) or the 1-D TV of the flattened image (algs.py:170)
+            kind = _capi.NCVX_ME_TV if self.isotropic else _capi.NCVX_ME_TV_ANISO
+        else:
+            kind = _capi.NCVX_MC_TV if self.isotropic else _capi.NCVX_MC_TV_ANISO
         return {**base, "ncvx_kind": kind,
                 "ncvx_lambda": self.lamda, "ncvx_gamma": self.gamma, "ncvx_niter": int(self.niter),
                 "ncvx_rtol": self.rtol if self.Op2 is None else 0.0,

@@ -500,9 +500,56 @@ def tv_prox_fgp(x, gamma, niter, step=0.125, betas=None, rtol=0.0, momentum="unl
     return (out, (p, q)) if return_dual else out
 
 
+def tv1d_value(x):
+    """1-D total variation of the vector(s) on the last axis: ``sum |x[i+1] - x[i]|``."""
+    return np.sum(np.abs(np.diff(x, axis=-1)), axis=-1)
+
+
+def tv1d_prox_fgp(x, gamma, niter, step=0.25, betas=None, rtol=0.0, momentum="unlocbox"):
+    """``prox_{gamma*TV_1D}(x)`` of a VECTOR by ``niter`` fast-gradient-projection dual iterations -- what ``pyproximal.TV`` does for
+    ``len(dims) == 1``, which is how ``algs.L2_ncvx_tv`` builds the inner prox of its ANISOTROPIC ME-TV branch: a 1-D TV over the flattened
+    image, ``TV((np.prod(dims),), 1., niter, rtol)`` (``algs.py:170``) [upstream: UNLocBoX prox_tv1d; parity unpinned].  The same loop as
+    :func:`tv_prox_fgp` with one dual component, forward differences ``d[i] = sol[i+1] - sol[i]`` (0 at the end), dual step ``step / gamma`` with
+    ``step = 1/4`` (1 / (2 ndim) where the 2-D prox has 1/8), projection onto ``|r| <= 1``; same momentum table, same early exit."""
+    x = np.asarray(x)
+    if x.ndim != 1:
+        raise ValueError("one vector at a time (the early exit is per image)")
+    dt = x.dtype
+    gamma = dt.type(gamma)
+    c = dt.type(step) / gamma
+    if betas is None:
+        betas = fgp_betas(niter, momentum)
+    betas = np.asarray(betas, dtype=dt)
+    rr = np.zeros_like(x)
+    p = np.zeros_like(x)
+    one = dt.type(1)
+
+    def div1(r):            # r[i] - r[i-1], the last entry of r taken as zero (no difference across the end)
+        d = np.zeros_like(r)
+        d[:-1] += r[:-1]
+        d[1:] -= r[:-1]
+        return d
+    prev_obj = None
+    for k in range(niter):
+        sol = x - gamma * div1(rr)
+        if rtol > 0.0:
+            obj = 0.5 * float(np.sum((x - sol) ** 2)) + float(gamma) * float(tv1d_value(sol))
+            rel = abs(obj - prev_obj) / obj if (prev_obj is not None and obj > 0) else 2 * rtol
+            prev_obj = obj
+            if rel < rtol:
+                return sol
+        d = np.zeros_like(sol)
+        d[:-1] = sol[1:] - sol[:-1]
+        r = rr - c * d
+        pn = r / np.maximum(one, np.abs(r))
+        rr = pn + betas[k] * (pn - p)
+        p = pn
+    return x - gamma * div1(rr)
+
+
 class TV(_Prox):
     """``sigma * TV_iso(x)`` -- ``pyproximal.TV(dims=img.shape, sigma=tau, niter=niter_tv)``
-    (``prox_lmc_deconv.py:122``)."""
+    (``prox_lmc_deconv.py:122``).  One-element ``dims``: the 1-D TV of a vector (``algs.py:170``)."""
 
     def __init__(self, dims, sigma=1.0, niter=10, rtol=0.0, step=0.125, momentum="unlocbox"):
         super().__init__(None, False)
@@ -514,9 +561,13 @@ class TV(_Prox):
         self.momentum = momentum
 
     def __call__(self, x):
+        if len(self.dims) == 1:
+            return self.sigma * float(tv1d_value(np.asarray(x).ravel()))
         return self.sigma * float(tv_value(np.asarray(x).reshape(self.dims)))
 
     def prox(self, x, tau):
+        if len(self.dims) == 1:          # step 1 / (2 ndim) / 2 as upstream: 1/4 in 1-D where the 2-D default is 1/8
+            return tv1d_prox_fgp(np.asarray(x).ravel(), self.sigma * tau, self.niter, step=2 * self.step, rtol=self.rtol, momentum=self.momentum)
         out = tv_prox_fgp(np.asarray(x).reshape(self.dims), self.sigma * tau, self.niter,
                           step=self.step, rtol=self.rtol, momentum=self.momentum)
         return out.ravel()
@@ -609,8 +660,10 @@ class L2NcvxTV(_Prox):
         self.niter = niter
         if Op2 is not None:
             self.g_gamma = L1(1.0)                       # algs.py:166
-        else:
+        elif isotropic:
             self.g_gamma = TV(self.dims, 1.0, niter, **(tv_kwargs or {}))   # algs.py:169
+        else:                                            # algs.py:170: a 1-D TV over the flattened image
+            self.g_gamma = TV((int(np.prod(self.dims)),), 1.0, niter, **(tv_kwargs or {}))
 
     def __call__(self, x):                               # algs.py:173-190
         Op2x = self.Op2.matvec(x) if self.Op2 is not None else x

@@ -354,6 +354,44 @@ def gen_algs_aniso(out):
     np.savez_compressed(out, **d)
 
 
+def gen_algs_aniso_me(out):
+    """Fourth golden set: the ANISOTROPIC ME-TV branch of the reference's ``L2_ncvx_tv`` (``isotropic=False``, ``Op2 = None``): its inner prox is a 1-D TV
+    over the flattened image, ``pyproximal.TV((np.prod(dims),), 1., niter, rtol)`` (algs.py:170) -- the reference's own class code, with the oracle's 1-D
+    restatement standing in for pyproximal's (``lmc_oracle.tv1d_prox_fgp``; upstream arithmetic unpinned like every pyproximal operator).  Value, gradient,
+    prox (incl. the warm-started second call) and a short MYULA trajectory driven by the class, at the class's own ``rtol = 1e-4`` and at ``rtol = 0``."""
+    A = load_ref("algs")
+    d = {}
+    sigma, tau_reg = 0.75, 0.3
+    L = 1.0 / sigma ** 2
+    gamma_myula = 1.0 / L
+    tau_myula = 0.2 * gamma_myula
+    tau0 = 0.95 / L
+    for tag, ny, nx, k, seed, gam, niter in [("a", 16, 24, 5, 0, 15.0, 30), ("b", 24, 136, 5, 1, 4.0, 20)]:
+        img, h, Hop, y = deconv_problem(ny, nx, k, sigma, seed)
+        d[f"{tag}_img"], d[f"{tag}_h"], d[f"{tag}_y"] = img, h, y
+        d[f"{tag}_meta"] = np.array([ny, nx, k, seed, gam, niter])
+        x0 = np.zeros(ny * nx)
+        for rt, rtol in (("rtol1e-4", 1e-4), ("rtol0", 0.0)):
+            HONOUR_RTOL[0] = rtol > 0
+            mk = lambda: A.L2_ncvx_tv(dims=(ny, nx), Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=gam, isotropic=False, niter=niter,
+                                      rtol=1e-4, warm=True)
+            xt = (img + np.random.default_rng(500 + seed).normal(0, 5.0, img.shape)).ravel()
+            me = mk()
+            d[f"{tag}_x"] = xt
+            d[f"{tag}_grad_{rt}"], d[f"{tag}_val_{rt}"] = me.grad(xt.copy()), np.array(me(xt.copy()))
+            vp = (img + np.random.default_rng(600 + seed).normal(0, 5.0, img.shape)).ravel()
+            mep = mk()
+            d[f"{tag}_prox_in"] = vp
+            d[f"{tag}_prox_out1_{rt}"] = mep.prox(vp.copy(), tau0)
+            d[f"{tag}_prox_out2_{rt}"] = mep.prox((vp + 1.0).copy(), tau0)
+            d[f"{tag}_myula_{rt}"] = A.MoreauYosidaUnadjustedLangevin(mk(), O.TV((ny, nx), sigma=tau_reg, niter=10), tau=tau_myula, gamma=gamma_myula,
+                                                                      x0=x0, niter=6, seed=seed)
+    HONOUR_RTOL[0] = False
+    d["params"] = np.array([sigma, tau_reg, tau_myula, gamma_myula, tau0])
+    d["versions"] = versions()
+    np.savez_compressed(out, **d)
+
+
 def gen_pywt(out):
     """Independent check of the Haar-l1 prox (BASELINE config 5's prior) with PyWavelets from the conda interpreter."""
     py39 = "/opt/conda/bin/python3.9"
@@ -385,6 +423,8 @@ if __name__ == "__main__":
     gen_prox(os.path.join(HERE, "prox.npz"))
     gen_algs(os.path.join(HERE, "algs.npz"))
     gen_algs_rtol(os.path.join(HERE, "algs_rtol.npz"))
+    if "--aniso-me" in sys.argv or not os.path.exists(os.path.join(HERE, "algs_aniso_me.npz")):
+        gen_algs_aniso_me(os.path.join(HERE, "algs_aniso_me.npz"))
     gen_algs_aniso(os.path.join(HERE, "algs_aniso.npz"))
     gen_chambolle(os.path.join(HERE, "tv_chambolle.npz"))
     gen_pywt(os.path.join(HERE, "haar_pywt.npz"))

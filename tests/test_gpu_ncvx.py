@@ -97,11 +97,63 @@ def test_mc_tv_large_image_all_kernels_agree(la):
     assert rel(gm, -0.3 * mco.grad_moreau(x0[0].ravel())) < 1e-4
 
 
-def test_unbuilt_branches_raise(la):
-    shape = (8, 8)
-    H = la.Convolve2D(shape, np.ones((5, 5)) / 25)
-    with pytest.raises(NotImplementedError):      # anisotropic ME-TV: a 1-D TV over the flattened image (algs.py:170)
-        la.L2_ncvx_tv(dims=shape, Op=H, b=np.zeros(64), isotropic=False)
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_anisotropic_me_tv_matches_reference_class(la, golden, tag):
+    """The anisotropic ME-TV branch (isotropic=False without Op2: a Moreau envelope of the 1-D TV of the FLATTENED image, algs.py:170) against
+    outputs of the reference's own class (tests/golden/algs_aniso_me.npz): value, gradient, prox and the MYULA trajectory it drives, with the
+    inner prox's exit as the reference configures it (rtol = 1e-4) and switched off (rtol = 0)."""
+    g = golden("algs_aniso_me.npz")
+    sigma, tau_reg, tau_myula, gamma_myula, tau0 = [float(v) for v in g["params"]]
+    ny, nx, k, seed, gam, niter = [float(v) for v in g[f"{tag}_meta"]]
+    ny, nx, k, seed, niter = int(ny), int(nx), int(k), int(seed), int(niter)
+    h, y = g[f"{tag}_h"], g[f"{tag}_y"]
+    H = la.Convolve2D((ny, nx), h, offset=(k // 2, k // 2))
+    xt = g[f"{tag}_x"]
+    l2o = O.L2(Op=O.Convolve2D((ny, nx), h, offset=(k // 2, k // 2)), b=y.ravel(), sigma=1 / sigma ** 2)
+    scale = (1 / sigma ** 2) * (np.linalg.norm(l2o.Op.rmatvec(l2o.Op.matvec(xt))) + np.linalg.norm(l2o.Op.rmatvec(y.ravel())))
+    for rt, rtol in (("rtol1e-4", 1e-4), ("rtol0", 0.0)):
+        mk = lambda: la.L2_ncvx_tv(dims=(ny, nx), Op=H, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=gam, isotropic=False, niter=niter, rtol=rtol)
+        me = mk()
+        got, ref = me.grad(xt.copy()), g[f"{tag}_grad_{rt}"]
+        assert np.linalg.norm(got - ref) < 2e-7 * scale and rel(got, ref) < 1e-4, (rt, rel(got, ref))
+        val = float(g[f"{tag}_val_{rt}"])
+        assert abs(me(xt.copy()) - val) < 1e-5 * abs(val)
+        vp = g[f"{tag}_prox_in"]
+        assert rel(mk().prox(vp.copy(), tau0), g[f"{tag}_prox_out1_{rt}"]) < 1e-4
+        gx = g[f"{tag}_myula_{rt}"]
+        out = la.MoreauYosidaUnadjustedLangevin(mk(), la.TV((ny, nx), sigma=tau_reg, niter=10), np.zeros(ny * nx), tau=tau_myula, gamma=gamma_myula,
+                                                niter=gx.shape[0], seed=seed, rng="pcg64")
+        assert rel(out, gx) < 5e-5, (rt, rel(out, gx))
+
+
+def test_anisotropic_me_tv_many_chains_against_the_checker(la):
+    """... and over several chains at once with injected noise (each chain exits its 1-D prox in its own pass): against the CPU checker's class."""
+    rng = np.random.default_rng(12)
+    shape = (24, 72)
+    img = np.zeros(shape); img[6:18, 10:50] = 150.0
+    img += np.linspace(0, 20, shape[1])[None, :]
+    h = np.ones((5, 5)) / 25
+    y = O.blur(img, h, (2, 2)) + rng.normal(0, 0.75, shape)
+    C_, nit = 3, 3
+    x0 = img[None] + rng.normal(0, [[[2.0]], [[8.0]], [[25.0]]], (C_,) + shape)
+    noise = rng.standard_normal((nit, C_) + shape)
+    sig, gam_m, tau = 0.75, 0.5625, 0.1125
+    for rtol in (1e-4, 0.0):
+        pf = la.L2_ncvx_tv(dims=shape, Op=la.Convolve2D(shape, h, offset=(2, 2)), b=y.ravel(), sigma=1 / sig ** 2, lamda=0.3, gamma=15.0, isotropic=False,
+                           niter=40, rtol=rtol)
+        of = O.L2NcvxTV(shape, Op=O.Convolve2D(shape, h, (2, 2)), b=y.ravel(), sigma=1 / sig ** 2, lamda=0.3, gamma=15.0, isotropic=False, niter=40,
+                        tv_kwargs={"rtol": rtol})
+        otv = O.TV(shape, sigma=0.3, niter=10)
+        smp = la.MYULASampler(pf, la.TV(shape, sigma=0.3, niter=10), shape, n_chains=C_, tau=tau, gamma=gam_m, noise="injected")
+        smp.set_state(x0)
+        smp.step(nit, noise=noise)
+        got = smp.get_state().cpu().numpy()
+        ref = np.stack([O.myula(of, otv, x0[c].ravel(), tau, gam_m, niter=nit, noise=[noise[i, c].ravel() for i in range(nit)])[-1].reshape(shape)
+                        for c in range(C_)])
+        assert rel(got, ref) < 2e-5, (rtol, rel(got, ref))
+        f, _ = smp.energies()
+        fref = np.array([of(got[c].ravel().astype(np.float64)) for c in range(C_)])
+        assert np.allclose(f.cpu().numpy(), fref, rtol=5e-5)
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])

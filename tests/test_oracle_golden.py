@@ -307,3 +307,31 @@ def test_l2_ncvx_tv_anisotropic_mc_tv_matches_reference_class(golden, tag):
     gx = g[f"{tag}_ulpda"]
     xs = O.ulpda(mk(), O.L21(ndim=2, sigma=tau_reg), Gop, np.zeros(ny * nx), tau0, mu0, theta=1.0, niter=gx.shape[0], seed=seed, gfirst=False)
     assert rel(xs, gx) < 5e-5, rel(xs, gx)
+
+
+# ---------------------------------------------------------------- anisotropic ME-TV (fourth golden set)
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_anisotropic_me_tv_oracle_matches_reference_class(golden, tag):
+    """algs_aniso_me.npz: the reference's own ``L2_ncvx_tv(isotropic=False)`` without ``Op2`` -- a Moreau envelope of the 1-D TV of the
+    flattened image (algs.py:170) -- driven with the checker's 1-D prox: the checker's class reproduces value, gradient and MYULA
+    trajectory exactly, and its prox (CG where the reference runs LSQR) to the solvers' tolerance, at rtol = 1e-4 and at rtol = 0."""
+    g = golden("algs_aniso_me.npz")
+    sigma, tau_reg, tau_myula, gamma_myula, tau0 = (float(v) for v in g["params"])
+    ny, nx, k, seed, gam, niter = g[f"{tag}_meta"]
+    ny, nx, k, seed, niter = int(ny), int(nx), int(k), int(seed), int(niter)
+    Hop = O.Convolve2D((ny, nx), g[f"{tag}_h"], offset=(k // 2, k // 2))
+    y = g[f"{tag}_y"]
+    for rt, rtol in (("rtol1e-4", 1e-4), ("rtol0", 0.0)):
+        mk = lambda: O.L2NcvxTV(dims=(ny, nx), Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2, lamda=tau_reg, gamma=float(gam), isotropic=False, niter=niter,
+                                tv_kwargs={"rtol": rtol})
+        me = mk()
+        xt = g[f"{tag}_x"]
+        np.testing.assert_allclose(me.grad(xt.copy()), g[f"{tag}_grad_{rt}"], rtol=1e-12, atol=1e-10)
+        assert abs(me(xt.copy()) - float(g[f"{tag}_val_{rt}"])) <= 1e-10 * abs(float(g[f"{tag}_val_{rt}"]))
+        mep = mk()
+        vp = g[f"{tag}_prox_in"]
+        assert np.linalg.norm(mep.prox(vp.copy(), tau0) - g[f"{tag}_prox_out1_{rt}"]) <= 1e-4 * np.linalg.norm(g[f"{tag}_prox_out1_{rt}"])
+        xs = O.myula(mk(), O.TV((ny, nx), sigma=tau_reg, niter=10), np.zeros(ny * nx), tau_myula, gamma_myula, niter=6, seed=seed)
+        np.testing.assert_allclose(xs, g[f"{tag}_myula_{rt}"], rtol=1e-12, atol=1e-10)
+    if tag == "a":   # the exit is in the fixtures (case b's few passes never reach it)
+        assert np.linalg.norm(g["a_grad_rtol1e-4"] - g["a_grad_rtol0"]) > 1e-6 * np.linalg.norm(g["a_grad_rtol0"])
