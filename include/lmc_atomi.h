@@ -167,6 +167,14 @@ typedef struct lmc_problem {
   int32_t eprox_kind;             /* lmc_eprox_kind */
   float eprox_p0, eprox_p1;
   int32_t eprox_scale_mask;
+  /* Array-valued epsg (algs.py:509,539-542: "float or np.ndarray"; the prox parameter at algs.py:569 is then the array epsg * gamma, which the
+   * closed-form proxes broadcast -- one weight per right-hand side, i.e. per chain here, or per pixel).  NULL = scalar epsg only.  Device array;
+   * the prox parameter of chain c, pixel i is  epsg * gamma * prox_scale[c * prox_scale_chain_stride + i * prox_scale_pixel_stride]
+   * (strides in elements: (0, 1) per pixel, (1, 0) per chain, (H*W, 1) both).  MYULA with LMC_PRIOR_L2 / L1 / EPROX only (the prox is evaluated by
+   * one launch before the fused step, which consumes it); LMC_E_UNSUPPORTED for the other priors and samplers.  Must outlive the sampler. */
+  const float* prox_scale;
+  int64_t prox_scale_chain_stride;
+  int32_t prox_scale_pixel_stride;
 } lmc_problem;
 
 /* ---- library ------------------------------------------------------------------------- */

@@ -66,6 +66,7 @@ class lmc_problem(C.Structure):
         ("moments_bg_workgroups", C.c_int32),
         ("graph_replay", C.c_int32),
         ("eprox_kind", C.c_int32), ("eprox_p0", C.c_float), ("eprox_p1", C.c_float), ("eprox_scale_mask", C.c_int32),
+        ("prox_scale", C.c_void_p), ("prox_scale_chain_stride", C.c_int64), ("prox_scale_pixel_stride", C.c_int32),
     ]
 
 

@@ -66,6 +66,10 @@ class MYULASampler:
         # launch policy of this sampler (lmc_problem, ABI 3): dict with any of iterations_per_launch (0 auto / 1 / 2), moments_overlap (0 auto /
         # 1 / -1), moments_bg_workgroups, graph_replay, tv_exit_path (1 = the pass-by-pass early exit)
         opts.update(policy or {})
+        self.epsg = epsg
+        if np.asarray(epsg).size > 1:      # array-valued epsg (algs.py:509,539-542): the prox parameter epsg * gamma is an array that the prox broadcasts
+            opts["prox_scale"] = self._epsg_array(epsg)
+            epsg = 1.0
         self._problem = _Problem(self.dims, _data_descriptor(proxf), _prior_descriptor(proxg), self.device, options=opts)
         cfg = _capi.lmc_myula_config()
         cfg.struct_size = C.sizeof(_capi.lmc_myula_config)
@@ -85,6 +89,23 @@ class MYULASampler:
             _capi.check(getattr(_dev.lib(), self._create_fn)(C.byref(cfg), C.byref(self._h)))
 
     _create_fn = "lmc_myula_create"
+
+    def _epsg_array(self, epsg):
+        """Device copy + (chain, pixel) strides of an array-valued ``epsg``.  The reference hands ``epsg * gamma`` to ``proxg.prox`` (algs.py:569), whose
+        closed forms broadcast it against ``x``: one weight per pixel of a flattened image (``x`` of shape ``(n,)``), one per right-hand side = per chain
+        (``x`` of shape ``(n, nrhs)``, ``epsg`` of shape ``(nrhs,)``), or both.  Here: ``(H*W,)`` / ``(H, W)`` per pixel, ``(n_chains,)`` per chain,
+        ``(n_chains, H*W)`` / ``(n_chains, H, W)`` both."""
+        e = np.asarray(epsg, dtype=np.float32)
+        n = self.dims[0] * self.dims[1]
+        if e.size == n and e.shape in ((n,), self.dims):
+            cs, ps = 0, 1
+        elif e.shape == (self.n_chains,):
+            cs, ps = 1, 0
+        elif e.size == self.n_chains * n and e.shape[0] == self.n_chains:
+            cs, ps = n, 1
+        else:
+            raise ValueError(f"epsg of shape {e.shape} matches neither the image {self.dims}, nor the {self.n_chains} chains, nor both")
+        return _dev.to_dev(np.ascontiguousarray(e.ravel()), self.device), cs, ps
 
     # -- lifetime ------------------------------------------------------------------------
     def close(self):
@@ -416,7 +437,7 @@ def MoreauYosidaUnadjustedLangevin(proxf, proxg, x0, tau=None, gamma=.1, epsg=1.
                   '---------------------------------------------------------\n'
                   'Proximal operator (f): %s\nProximal operator (g): %s\n'
                   'tau = %s\tgamma=%10e\nepsg = %s\tniter = %d\tchains = %d\n' %
-                  (type(proxf), type(proxg), str(tau), gamma, str(epsg), niter, C_))
+                  (type(proxf), type(proxg), str(tau), gamma, str(epsg) if np.asarray(epsg).size == 1 else 'Multi', niter, C_))     # algs.py:539-542
             print('   Itn       x[0]          f           g     J = f + eps*g')
         if not many:
             samples = np.empty((niter, n), dtype=np.asarray(x0).dtype if not isinstance(x0, torch.Tensor) else np.float32)
@@ -436,7 +457,7 @@ def MoreauYosidaUnadjustedLangevin(proxf, proxg, x0, tau=None, gamma=.1, epsg=1.
                 if show and (it < 10 or niter - it < 10 or it % max(niter // 10, 1) == 0):
                     f, g = smp.energies()
                     pf, pg = float(f[0]), float(g[0])
-                    print('%6g  %12.5e  %10.3e  %10.3e  %10.3e' % (it + 1, samples[it][0], pf, pg, pf + epsg * pg))
+                    print('%6g  %12.5e  %10.3e  %10.3e  %10.3e' % (it + 1, samples[it][0], pf, pg, pf + float(np.sum(epsg * pg))))   # algs.py:582
             if show:
                 print('\nTotal time (s) = %.2f' % (time.time() - tstart))
                 print('---------------------------------------------------------\n')
@@ -463,7 +484,7 @@ def MoreauYosidaUnadjustedLangevin(proxf, proxg, x0, tau=None, gamma=.1, epsg=1.
                 f, g = smp.energies()
                 x00 = float(smp.get_state()[0, 0, 0])
                 print('%6g  %12.5e  %10.3e  %10.3e  %10.3e' % (done, x00, float(f.mean()), float(g.mean()),
-                                                              float((f + epsg * g).mean())))
+                                                              float((f + (epsg if np.asarray(epsg).size == 1 else float(np.sum(epsg))) * g).mean())))
         s1, s2, cnt = smp.moments()
         f, g = smp.energies()
         state = smp.get_state()

@@ -81,6 +81,8 @@ struct Problem {
   int cheb_pair = 1;        // two Chebyshev iterations per launch: 0 never, 1 where they pay, 2 wherever covered
   int eprox_kind = 0, eprox_mask = 0;   // LMC_PRIOR_EPROX: closed form, which parameters scale with the prox parameter
   float eprox_p0 = 0.f, eprox_p1 = 0.f;
+  const float* prox_scale = nullptr;   // array-valued epsg: per-chain / per-pixel multiplier of the prox parameter (closed-form priors of MYULA only)
+  int64_t prox_scale_cs = 0, prox_scale_ps = 0;
   int variant = 0;          // 0: the library default (g_variant)
   float implicit_tol = 0.f; // 0: the library default (g_cg_tol); < 0: disabled
 };
@@ -285,6 +287,12 @@ int load_problem(const lmc_problem* p, Problem& q) {
   if (p->step_variant < 0 || p->step_variant > 7 || p->step_variant == 2)
     return fail(LMC_E_INVALID, "step_variant %d: 0 (library default), 1 tile, 3 split, 4 point, 5 block, 6 rows, 7 pipe", p->step_variant);
   q.variant = p->step_variant;
+  if (p->prox_scale) {
+    if (p->prior_kind != LMC_PRIOR_L2 && p->prior_kind != LMC_PRIOR_L1 && p->prior_kind != LMC_PRIOR_EPROX)
+      return fail(LMC_E_UNSUPPORTED, "prox_scale (array-valued epsg) is built for the closed-form priors (l2, l1, prox.py closed forms) only");
+    if (p->prox_scale_chain_stride < 0 || p->prox_scale_pixel_stride < 0) return fail(LMC_E_INVALID, "prox_scale strides must be >= 0");
+    q.prox_scale = p->prox_scale; q.prox_scale_cs = p->prox_scale_chain_stride; q.prox_scale_ps = p->prox_scale_pixel_stride;
+  }
   q.tv_warm = (p->tv_warm != 0 && p->prior_kind == LMC_PRIOR_TV_ISO) ? 1 : 0;
   if (!(p->implicit_tol == p->implicit_tol)) return fail(LMC_E_INVALID, "implicit_tol is NaN");
   q.implicit_tol = p->implicit_tol;
@@ -981,6 +989,7 @@ int lmc_fused_eval(const lmc_problem* prob, const float* x_dev, float* out_dev, 
   if (rc) return rc;
   if (!x_dev || !out_dev || x_dev == out_dev) return fail(LMC_E_INVALID, "bad pointers (in-place not allowed)");
   if (n_img < 1 || n_img > (1 << 24)) return fail(LMC_E_INVALID, "bad n_img %lld", (long long)n_img);
+  if (q.prox_scale) return fail(LMC_E_UNSUPPORTED, "prox_scale (array-valued epsg) belongs to the MYULA sampler");
   lmc::StepArgs A;
   rc = make_step_args(q, a, t, b, pt, 0.f, A);
   if (rc) return rc;
@@ -1197,7 +1206,7 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
     if (e == hipSuccess) e = hipMalloc(&s->tvstate[1], 4 * nbytes);
   }
   if (e == hipSuccess && s->prob.ncvx_kind == LMC_NCVX_ME_TV) e = hipMalloc(&s->extra, nbytes);
-  if (e == hipSuccess && s->prob.prior_kind == LMC_PRIOR_HAAR_L1) e = hipMalloc(&s->pxbuf, nbytes);
+  if (e == hipSuccess && (s->prob.prior_kind == LMC_PRIOR_HAAR_L1 || s->prob.prox_scale)) e = hipMalloc(&s->pxbuf, nbytes);
   if (e == hipSuccess && s->prob.tv_rtol > 0.f && s->base.prior_kind == LMC_PRIOR_TV_ISO) {
     if (s->prob.tv_warm) { lmc_sampler_destroy(s); return fail(LMC_E_UNSUPPORTED, "tv_rtol > 0 and tv_warm exclude each other"); }
     const int mode = tv_prior_rt_mode(s->prob, s->base, s->epsg * s->gamma);     // 1: inside the fused launch, 0: prox alone, 2: pass by pass
@@ -1219,6 +1228,7 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
     s->pol_bg_wgs = q.moments_bg_wgs > 0 ? q.moments_bg_wgs : env_int("LMC_MOMENTS_BG_WGS", -1);
     s->pol_graph = q.graph_replay ? 1 : (env_int("LMC_GRAPH", 0) == 1);
     s->pol_side_lowprio = env_int("LMC_MOMENTS_SIDE_PRIO", 1) != 0;
+    if (q.prox_scale) { s->pol_pair = 0; s->pol_blockpair = 0; s->pol_graph = 0; }   // array-valued epsg: the prox is its own launch before every step
   }
   if (e == hipSuccess && s->prob.tv_warm) {
     lmc::StepArgs probe = s->base;
@@ -1653,6 +1663,13 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
       A.prior_kind = LMC_PRIOR_NONE;
       A.prox_ext = s->pxbuf;
     }
+    if (s->prob.prox_scale && A.prior_kind != LMC_PRIOR_NONE) {   // array-valued epsg: prox_{epsg[c,i] gamma g} first, consumed as a ready-made prox
+      const Problem& q = s->prob;
+      HIP_TRY(lmc::launch_prior_prox_scaled(q.prior_kind, q.eprox_kind, A.x_in, s->pxbuf, s->C, (int64_t)q.H * q.W, q.prox_scale, q.prox_scale_cs, q.prox_scale_ps,
+                                            s->epsg * s->gamma, q.prior_sigma, q.eprox_p0, q.eprox_p1, q.eprox_mask, st));
+      A.prior_kind = LMC_PRIOR_NONE;
+      A.prox_ext = s->pxbuf;
+    }
     if (stepped) {
       e = hipSuccess;
     } else if (s->tvwarm[0]) {     // warm-started TV prox: the dual of the previous iteration in, this iteration's out
@@ -1703,6 +1720,7 @@ int lmc_mymala_create(const lmc_myula_config* cfg, lmc_sampler** out) {
   *out = nullptr;
   if (s->tvwarm[0]) { lmc_sampler_destroy(s); return fail(LMC_E_UNSUPPORTED, "MYMALA needs a proposal mean that is a function of x alone: tv_warm is not allowed"); }
   if (s->rtmp || s->rt_tv.kc) { lmc_sampler_destroy(s); return fail(LMC_E_UNSUPPORTED, "MYMALA with tv_rtol > 0 is not built (use the fixed-count prox, tv_rtol = 0)"); }
+  if (s->prob.prox_scale) { lmc_sampler_destroy(s); return fail(LMC_E_UNSUPPORTED, "MYMALA takes a scalar epsg (the reference's array-valued epsg is MYULA's, algs.py:509)"); }
   s->kind = 2;
   const size_t nbytes = sizeof(float) * (size_t)s->C * s->prob.H * s->prob.W;
   hipError_t e = hipMalloc(&s->mx, nbytes);

@@ -28,6 +28,8 @@ hipError_t launch_gradient(const float* x, float* out, int64_t n_img, int H, int
 hipError_t launch_dual_project(const float* y, float* out, int64_t n_img, int H, int W, float radius, int iso,
                                hipStream_t st);
 hipError_t launch_eprox(int kind, const float* x, float* out, int64_t n, float p0, float p1, hipStream_t st);
+hipError_t launch_prior_prox_scaled(int prior, int kind, const float* x, float* out, int64_t n_chains, int64_t img, const float* scale, int64_t cs, int64_t ps,
+                                    float pt, float sigma, float p0, float p1, int mask, hipStream_t st);
 hipError_t launch_haar_prox(const float* x, float* out, int64_t n_img, int H, int W, float thr, hipStream_t st);
 hipError_t launch_chain_probes(const float* x, float* out, int64_t n_img, int H, int W, int ph, int pw, hipStream_t st);
 hipError_t launch_haar_value(const float* x, int64_t n_img, int H, int W, float sigma, double* val, hipStream_t st);

@@ -115,6 +115,10 @@ class _Problem:
             p.eprox_kind = int(prior["eprox_kind"])
             p.eprox_p0, p.eprox_p1 = float(prior["eprox_p0"]), float(prior["eprox_p1"])
             p.eprox_scale_mask = int(prior.get("eprox_scale_mask", 0))
+        if opt.get("prox_scale") is not None:     # array-valued epsg (MYULA): device array + (chain, pixel) strides
+            sc, cs, ps = opt["prox_scale"]
+            self._keep.append(sc)
+            p.prox_scale, p.prox_scale_chain_stride, p.prox_scale_pixel_stride = _dev.ptr(sc), int(cs), int(ps)
         self.c = p
 
     def eval(self, x, a, t, b, pt):

@@ -392,6 +392,51 @@ def gen_algs_aniso_me(out):
     np.savez_compressed(out, **d)
 
 
+def gen_epsg_array(out):
+    """Fifth golden set: the reference's MYULA loop (algs.py:559-570) with an ARRAY-valued ``epsg`` (algs.py:509,539-542) -- the prox parameter
+    ``epsg * gamma`` it hands to ``proxg.prox`` is then an array, which a closed-form prox broadcasts: per pixel for the flattened image (``x`` of shape
+    ``(n,)``), per right-hand side for ``x`` of shape ``(n, nrhs)`` with ``epsg`` of shape ``(nrhs,)``.  Priors: the oracle's l1 and l2 (pyproximal.L1 / L2
+    restated) and the reference's own ``prox.prox_laplace`` wrapped as a prox operator."""
+    A = load_ref("algs")
+    P = load_ref("prox")
+    d = {}
+    sigma = 0.75
+    L = 1.0 / sigma ** 2
+    gamma_myula = 1.0 / L
+    tau_myula = 0.2 * gamma_myula
+    ny, nx, k, seed, nit = 16, 40, 5, 3, 5
+    img, h, Hop, y = deconv_problem(ny, nx, k, sigma, seed)
+    n = ny * nx
+    f = O.L2(Op=Hop, b=y.ravel(), sigma=1 / sigma ** 2)
+    rng = np.random.default_rng(77)
+    e_px = rng.uniform(0.2, 3.0, n)                       # one weight per pixel
+    d["img"], d["h"], d["y"], d["epsg_pixel"] = img, h, y, e_px
+    d["meta"] = np.array([ny, nx, k, seed, nit])
+
+    class Laplace:                                        # the reference's closed form as the prior's prox (as at prox_lmc.py:106,115)
+        def __init__(self, lam): self.lam = lam
+        def __call__(self, x): return self.lam * float(np.sum(np.abs(x)))
+        def prox(self, x, tau): return P.prox_laplace(x, tau * self.lam)
+
+    x0 = np.zeros(n)
+    for name, g in (("l1", O.L1(sigma=2.0)), ("l2", O.L2(sigma=0.05)), ("laplace", Laplace(1.5))):
+        d[f"pixel_{name}"] = A.MoreauYosidaUnadjustedLangevin(f, g, tau=tau_myula, gamma=gamma_myula, epsg=e_px, x0=x0, niter=nit, seed=seed)
+    # per right-hand side: x of shape (n, nrhs), a pointwise (Diagonal-free) data term so that grad broadcasts over the columns
+    nrhs = 3
+    e_rhs = np.array([0.5, 1.0, 4.0])
+    yv = y.ravel()[:, None]
+    class L2Id:                                           # f = sigma/2 ||x - y||^2 column by column
+        def __call__(self, x): return 0.5 / sigma ** 2 * float(np.sum((x - yv) ** 2))
+        def grad(self, x): return (x - yv) / sigma ** 2
+    X0 = np.zeros((n, nrhs))
+    d["epsg_rhs"] = e_rhs
+    for name, g in (("l1", O.L1(sigma=2.0)), ("l2", O.L2(sigma=0.05))):
+        d[f"rhs_{name}"] = A.MoreauYosidaUnadjustedLangevin(L2Id(), g, tau=tau_myula, gamma=gamma_myula, epsg=e_rhs, x0=X0, niter=nit, seed=seed)
+    d["params"] = np.array([sigma, tau_myula, gamma_myula])
+    d["versions"] = versions()
+    np.savez_compressed(out, **d)
+
+
 def gen_pywt(out):
     """Independent check of the Haar-l1 prox (BASELINE config 5's prior) with PyWavelets from the conda interpreter."""
     py39 = "/opt/conda/bin/python3.9"
@@ -426,6 +471,7 @@ if __name__ == "__main__":
     if "--aniso-me" in sys.argv or not os.path.exists(os.path.join(HERE, "algs_aniso_me.npz")):
         gen_algs_aniso_me(os.path.join(HERE, "algs_aniso_me.npz"))
     gen_algs_aniso(os.path.join(HERE, "algs_aniso.npz"))
+    gen_epsg_array(os.path.join(HERE, "epsg_array.npz"))
     gen_chambolle(os.path.join(HERE, "tv_chambolle.npz"))
     gen_pywt(os.path.join(HERE, "haar_pywt.npz"))
     for f in sorted(os.listdir(HERE)):

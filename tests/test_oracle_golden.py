@@ -335,3 +335,28 @@ def test_anisotropic_me_tv_oracle_matches_reference_class(golden, tag):
         np.testing.assert_allclose(xs, g[f"{tag}_myula_{rt}"], rtol=1e-12, atol=1e-10)
     if tag == "a":   # the exit is in the fixtures (case b's few passes never reach it)
         assert np.linalg.norm(g["a_grad_rtol1e-4"] - g["a_grad_rtol0"]) > 1e-6 * np.linalg.norm(g["a_grad_rtol0"])
+
+
+# ---------------------------------------------------------------- array-valued epsg (fifth golden set)
+def test_array_valued_epsg_oracle_matches_reference_loop(golden):
+    """epsg_array.npz: the reference's MYULA loop with ``epsg`` an array (algs.py:509,539-542,569) -- per pixel of the flattened image, and per
+    right-hand side for a state of shape (n, nrhs).  The checker's loop with the same array reproduces both to the last bit."""
+    g = golden("epsg_array.npz")
+    sigma, tau, gam = (float(v) for v in g["params"])
+    ny, nx, k, seed, nit = (int(v) for v in g["meta"])
+    f = O.L2(Op=O.Convolve2D((ny, nx), g["h"], offset=(k // 2, k // 2)), b=g["y"].ravel(), sigma=1 / sigma ** 2)
+
+    class Laplace:
+        def prox(self, x, t): return O.prox_laplace(x, t * 1.5)
+
+    for name, pr in (("l1", O.L1(sigma=2.0)), ("l2", O.L2(sigma=0.05)), ("laplace", Laplace())):
+        xs = O.myula(f, pr, np.zeros(ny * nx), tau, gam, epsg=g["epsg_pixel"], niter=nit, seed=seed)
+        np.testing.assert_array_equal(xs, g[f"pixel_{name}"])
+    yv = g["y"].ravel()[:, None]
+
+    class L2Id:
+        def grad(self, x): return (x - yv) / sigma ** 2
+
+    for name, pr in (("l1", O.L1(sigma=2.0)), ("l2", O.L2(sigma=0.05))):
+        xs = O.myula(L2Id(), pr, np.zeros((ny * nx, 3)), tau, gam, epsg=g["epsg_rhs"], niter=nit, seed=seed)
+        np.testing.assert_array_equal(xs, g[f"rhs_{name}"])
