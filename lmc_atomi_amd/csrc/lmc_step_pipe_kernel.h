@@ -301,7 +301,14 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
   // with few live stages therefore pairs every heavy wave with a pass-through one: L + N | T1 + T4 | T2 + T3 | C + T5 (measured: DESIGN 3.0r).
   int wave = hw_wave;
   if constexpr (RT && K == 10) {
-    if (kc <= 4) wave = hw_wave == 3 ? 6 : hw_wave == 4 ? 7 : hw_wave == 5 ? 4 : hw_wave == 6 ? 3 : hw_wave == 7 ? 5 : hw_wave;
+#ifndef LMC_RT_MAP
+#define LMC_RT_MAP 0
+#endif
+    if (kc <= 4) {
+      if (LMC_RT_MAP == 0) wave = hw_wave == 3 ? 6 : hw_wave == 4 ? 7 : hw_wave == 5 ? 4 : hw_wave == 6 ? 3 : hw_wave == 7 ? 5 : hw_wave;
+      else if (LMC_RT_MAP == 1) wave = hw_wave == 4 ? 6 : hw_wave == 6 ? 4 : hw_wave;                                              // L + C | T1 + T5 | T2 + T4 | T3 + N
+      else wave = hw_wave == 3 ? 6 : hw_wave == 4 ? 5 : hw_wave == 5 ? 4 : hw_wave == 6 ? 3 : hw_wave;                              // L + T5 | T1 + T4 | T2 + T3 | C + N
+    }
     else wave = hw_wave == 4 ? 6 : hw_wave == 6 ? 4 : hw_wave;        // more live stages: L + C | T1 + T5 | T2 + T4 | T3 + N
   }
   // column strip of this workgroup (blockIdx.y; one strip = the whole row when W <= 64 PXL): c0 is a GLOBAL column, LDS rows are indexed by lane
@@ -729,6 +736,12 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     for (int t = 0; t < T_end; t += 4) static_for<0, 4>([&](auto uu) { tick(uu, t + decltype(uu)::value); });
   } else {
     // ---------------- C: final primal step, combine, store --------------------------------------------------
+    // Two copies of the role (like the T role's): VM = this wave issues global LOADS (rows of the ME-TV prox image, injected noise).  Memory operations
+    // retire in order through one counter, so wherever a conditional load merges back the compiler waits for vmcnt(0) -- in a wave that also stores, that
+    // is a wait for its own stores of the previous tick, every tick (counters of the combine wave running alone: 55 % of its cycles in s_waitcnt, 529 ns
+    // per tick for 126 ns of arithmetic).  The copy without loads has no such wait.
+    auto c_role = [&](auto vm_tag) __attribute__((always_inline)) {
+    constexpr bool VM = decltype(vm_tag)::value;
     const float gam = A.tv.gamma;
     const float* const hin = lds + L::o_hand + (NT - 1) * 8 * BW;      // [2][4][BW], or [2][2][BW] in a chained launch
     constexpr int HSTR = CHAIN ? 2 * BW : 4 * BW;
@@ -751,7 +764,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int k = 0; k < PXL; ++k) exq[u][k] = 0.f;
-    if (A.extra) {
+    if (VM && A.extra) {
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int r = u - D;
@@ -763,7 +776,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       constexpr int NI = ((U - D) % 4 + 4) % 4;        // == o & 3  (t = 4m + U)
       const int o = t - D;
       if (state_only) { PIPE_TICK_SYNC(); return; }     // this link only advances the dual state (of this chain)
-      if (A.extra) {
+      if (VM && A.extra) {
         const int r3 = o + 3;
         gload_raw<PXL>(exq[(U + 3) & 3], A.extra + (size_t)chain * img + (size_t)min(max(r3, 0), H - 1) * W, c0, W, al);
       }
@@ -856,14 +869,14 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
             if (A.noise_mode == LMC_NOISE_PHILOX) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) xi[q] = slr[(NI * PXL + 4 * g + q) * 64];
-            } else if (A.noise_mode == LMC_NOISE_INJECTED) {
+            } else if (VM && A.noise_mode == LMC_NOISE_INJECTED) {
               const float* nrow = A.noise + (size_t)chain * img + go;
               if (al) {
                 const float4 v = *reinterpret_cast<const float4*>(nrow + c0 + 4 * g);
                 xi[0] = v.x; xi[1] = v.y; xi[2] = v.z; xi[3] = v.w;
               } else load4_dword_aligned(xi[0], xi[1], xi[2], xi[3], nrow, c0 + 4 * g, W);
             }
-            if (A.extra) {
+            if (VM && A.extra) {
               ex[0] = exq[U][4 * g]; ex[1] = exq[U][4 * g + 1]; ex[2] = exq[U][4 * g + 2]; ex[3] = exq[U][4 * g + 3];
               if constexpr (!AL) unshift4_dword_aligned(ex[0], ex[1], ex[2], ex[3], c0 + 4 * g, W);
             }
@@ -872,7 +885,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
             for (int q = 0; q < 4; ++q) {
               const float x = xo[4 * g + q];
               float gr = gv[4 * g + q];
-              if (A.extra) gr = fmaf(A.extra_coef, x - ex[q], gr);
+              if (VM && A.extra) gr = fmaf(A.extra_coef, x - ex[q], gr);
               ov[q] = fmaf(A.a, x, fmaf(-A.t, gr, fmaf(A.b, prox[4 * g + q], A.s * xi[q])));
             }
             gstore4(xout + go, c0 + 4 * g, st_lo, st_hi, al, ov[0], ov[1], ov[2], ov[3]);
@@ -898,6 +911,9 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
         if (lane == 0) unsafeAtomicAdd(A.rt_obj + (size_t)chain * A.rt_stride + A.rt_base + kc, tot);
       }
     }
+    };   // c_role
+    if (A.extra != nullptr || A.noise_mode == LMC_NOISE_INJECTED) c_role(std::true_type{});
+    else c_role(std::false_type{});
   }
 }
 
