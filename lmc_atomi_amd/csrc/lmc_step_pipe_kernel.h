@@ -471,13 +471,16 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       float R[PXL];
       {
         const bool rowok = r >= 0 && r < H;
+        const float rmask = rowok ? 1.f : 0.f;
         gfix_raw<PXL, AL>(ypre[U & 3], c0, W);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
           float acc = uv[0] * hxn[k];
 #pragma unroll
           for (int a = 1; a < KT; ++a) acc = fmaf(uv[a], hxw[kRing4 ? ((U - a) & 3) : a - 1][k], acc);
-          R[k] = (rowok && c0 + k < W) ? acc - ypre[U & 3][k] : 0.f;
+          // masked by a factor, not a select: a select on (row, column) turns into one exec-masked block per pixel (8 per tick: the wave's longest
+          // stretch of unpacked arithmetic and half of its scalar instructions); every operand is finite (clamped rows, zeroed ring rows)
+          R[k] = (acc - ypre[U & 3][k]) * ((AL ? c0 < W : c0 + k < W) ? rmask : 0.f);
         }
         if (A.f_out) {
 #pragma unroll
