@@ -387,12 +387,12 @@ def main():
         headline = (args.prior == "tv" and args.alg == "myula" and args.ncvx == "none" and args.data == "blur" and args.tv_iters == 10 and not args.tv_warm
                     and not args.tv_lagged and H == 512 and W == 512)
         if headline and not args.tv_rtol:
-            # what binds the K = 10 kernel is the vector ALU, not HBM: the bound of ITS instruction stream (ISA counts x measured issue times)
+            # what binds the K = 10 kernel is the vector ALU, not HBM: the bound of ITS instruction stream (VALU issue slots from the counters)
             out["roofline"]["valu_bound_ms"] = {
-                "perfectly_balanced": 1.34 * C / 1024.0, "whole_waves_on_simds": 1.52 * C / 1024.0,
-                "how": "per tick and role, VALU instructions of the ISA (scripts/isa_loops.py) x issue time per class (scripts/ubench/inst_rate.hip): 2593 ns of SIMD time per "
-                       "tick and CU = 648 per SIMD if it could be split evenly; with whole waves on SIMDs the busiest SIMD (T1 + T5) carries 710 ns; x 536 ticks x 4 "
-                       "rounds of 256 workgroups"}
+                "perfectly_balanced": 1.16 * C / 1024.0, "whole_waves_on_simds": 1.29 * C / 1024.0,
+                "how": "SQ_ACTIVE_INST_VALU (4-cycle issue slots) of the shipped kernel and of free-running single-role builds (profiles/r03_pipe_role_counters.txt): "
+                       "per tick L 165, T1 159, T2..T5 190.5 each, C 52, N 163 = 1281 slots per CU; 320 per SIMD (541 ns at 2.37 GHz) if it could be split evenly; with "
+                       "whole waves on SIMDs the busiest pair (L + T4) carries 355.5 (600 ns); x 536 ticks x 4 rounds of 256 workgroups"}
         if headline and not args.tv_rtol and world == 1 and os.environ.get("LMC_BENCH_AS_CONFIGURED", "1") != "0":
             # beside the headline (fixed K = 10 passes): the same chain AS THE REFERENCE IS CONFIGURED -- pyproximal.TV's default rtol = 1e-4, which
             # prox_lmc_deconv.py:122 leaves in force; the exit is decided on the device, chain by chain.  60 warm-up iterations: the pass counts

@@ -24,8 +24,9 @@ namespace lmc {
 // k2's arithmetic (1.876 ms), the same with stage k2's stores interleaved with its arithmetic behind scheduling barriers (1.799 ms), and the
 // two-team layout -- 16 waves of 4 pixels per lane, the teams' roles on complementary SIMDs, the column seam through LDS; exact -- at commit
 // 4183175 (1.811 ms).  Base: 1.749 ms.
-#ifdef LMC_EXP_NOBARRIER   // timing experiment: waves free-run (results are wrong)
-#define PIPE_TICK_SYNC() do {} while (0)
+#ifdef LMC_EXP_NOBARRIER   // timing experiment: waves free-run (results are wrong); a compiler-only fence keeps every LDS store alive (without it the stores of
+                           // a tick that the same wave overwrites two ticks later are dead, and the arithmetic behind them with them)
+#define PIPE_TICK_SYNC() asm volatile("" ::: "memory")
 #elif defined(LMC_EXP_SLEEP_MASK)   // timing experiment: the waves in the mask start every tick LMC_EXP_SLEEP_N x 64 cycles late (phase shift)
 #define PIPE_TICK_SYNC() do { __syncthreads(); if ((LMC_EXP_SLEEP_MASK >> wave) & 1) __builtin_amdgcn_s_sleep(LMC_EXP_SLEEP_N); } while (0)
 #else
