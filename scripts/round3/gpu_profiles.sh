@@ -20,6 +20,7 @@ else
   $P r03_ulpda --alg ulpda > /dev/null 2>&1 && echo ulpda done
   $P r03_ulpda7 --alg ulpda --blur-k 7 > /dev/null 2>&1 && echo ulpda7 done
   $P r03_metv --ncvx me --ncvx-iters 50 --ncvx-rtol 1e-4 --tv-rtol 1e-4 --warmup 30 > /dev/null 2>&1 && echo metv done
-  tags="ulpda ulpda7 metv"
+  $P r03_mymala --alg mymala > /dev/null 2>&1 && echo mymala done
+  tags="ulpda ulpda7 metv mymala"
 fi
 for t in $tags; do echo "=== $t"; head -6 gpurun_out/prof_r03_$t/summary.txt | cut -c1-200; grep -E "VALU busy|FETCH_SIZE|WRITE_SIZE" gpurun_out/prof_r03_$t/summary.txt | head -8; done
