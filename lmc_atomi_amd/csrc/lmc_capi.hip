@@ -1688,7 +1688,10 @@ int lmc_sampler_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, vo
     if (s->timing) HIP_TRY(hipEventRecord(s->ev[2 * s->last_launches + 1], st));
     s->cur ^= 1;
     if (s->moments && s->iteration >= s->burn_in && (s->iteration - s->burn_in) % s->thin == 0) {
-      if (overlap && k + 1 < n_iters) {   // reduce x[cur] on the side stream while the next step kernel runs
+      // ... unless the step kernel is a single launch of an HBM-heavy closed-form-prior kernel at full size: the two then share the memory system and the
+      // reduction outlasts the kernel whatever its workgroup count (blur + l2, 512 x 512 x 1024: in line 0.714 ms per iteration, beside it 0.73-0.83)
+      const bool beside = overlap && (s->pol_overlap > 0 || s->base.prior_kind == LMC_PRIOR_TV_ISO || (long long)per_iter <= (1LL << 25));
+      if (beside && k + 1 < n_iters) {   // reduce x[cur] on the side stream while the next step kernel runs
         HIP_TRY(hipEventRecord(s->ev_step, st));
         HIP_TRY(hipStreamWaitEvent(s->side, s->ev_step, 0));
         HIP_TRY(lmc::launch_moments_bg(s->x[s->cur], s->C, s->prob.H, s->prob.W, s->s1, s->s2, bg_wgs, s->side));

@@ -88,10 +88,15 @@ __device__ __forceinline__ void rows_load4(float (&dst)[4], const float* __restr
 // directly every 8th row so that rounding cannot drift).  The scale c_u^2 c_v^2 sigma_f is applied once.  Same update to rounding (tests).
 // EP: the prior is one of the closed-form elementwise proxes of prox.py (LMC_PRIOR_EPROX) -- instantiations of their own, so that the fifteen
 // closed forms (cube roots, square roots) cost the register-tight l2 / l1 / ready-made-prox kernels nothing.
-template <int PXL, int KT, bool DOT = false, int ULO = -1, int UHI = -1, bool AL = true, bool EP = false>
-__global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step_rows_kernel(const StepArgs P, const int band_rows, const int nbands) {
+// XLM: which of the optional per-pixel inputs the combine step LOADS -- bit 0 injected noise, bit 1 a ready-made prox (prox_ext), bit 2 the ME-TV prox
+// image (extra) -- fixed at compile time, or -1 = decided at run time.  A load under a run-time condition makes the compiler wait for vmcnt(0) where the
+// paths merge -- before every output store, i.e. for every x / y row prefetched for LATER steps and for the wave's previous stores (memory operations retire in
+// order through one counter): the prefetch distance was void.  The kernel below picks the copy for the two masks that matter (0: MYULA with Philox noise;
+// 3: a Chebyshev step, u_{k-1} through the noise input and the right-hand side as prox_ext) and keeps the run-time form for the rest.
+template <int PXL, int KT, bool DOT, int ULO, int UHI, bool AL, bool EP, int XLM>
+__device__ __forceinline__ void rows_body(const StepArgs& P, const int band_rows, const int nbands, float* const nz_lds) {
   using Gm = RowsGeom<PXL, KT>;
-  constexpr int HW = Gm::HW, LAG = Gm::LAG, PF = (PXL == 8 && KT == 7 && UHI == 5 && AL) ? 1 : Gm::PF;
+  constexpr int HW = Gm::HW, LAG = Gm::LAG, PF = (PXL == 8 && KT == 7 && (UHI == 5 || UHI == 6 || EP) && AL) ? 1 : Gm::PF;
   constexpr bool UNI = ULO >= 0;
   static_assert(!UNI || (UHI >= ULO && UHI < KT && !DOT), "uniform-box window");
   if constexpr (DOT) {
@@ -101,6 +106,9 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
   const int lane = threadIdx.x & 63;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int H = P.H, W = P.W;
+  const bool x_noise = XLM < 0 ? P.noise_mode == LMC_NOISE_INJECTED : (XLM & 1) != 0;
+  const bool x_prox = XLM < 0 ? P.prox_ext != nullptr : (XLM & 2) != 0;
+  const bool x_extra = XLM < 0 ? P.extra != nullptr : (XLM & 4) != 0;
   // Column strips (W > 64 PXL): a wave covers the columns [strip U - HALO, strip U - HALO + 64 PXL) of its band and writes the interior
   // [strip U, (strip + 1) U); the gradient of a pixel needs x within KT - 1 columns, so the HALO columns either side are recomputed, not exchanged.
   constexpr int HALO = 8, USTRIP = 64 * PXL - 2 * HALO;        // strips only ever run 8 pixels per lane (W > 512)
@@ -122,8 +130,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
 
   // 8 px / lane: the 32 normals of a quad row-group wait in a wave-private LDS slab (each lane reads back only what it
   // wrote, so no barrier) instead of 32 VGPRs -- the register file is the limit at 2 waves / SIMD.
-  constexpr bool kNzLds = PXL == 8;
-  __shared__ float nz_lds[kNzLds ? 4 * PXL * 4 * 64 : 1];
+  constexpr bool kNzLds = PXL == 8;        // nz_lds: [4 waves][PXL * 4][64] floats, declared by the kernel (one array for all copies of this body)
   float* const nzw = nz_lds + (kNzLds ? (threadIdx.x >> 6) * PXL * 4 * 64 + lane : 0);
   // general taps: A / G = residual / gradient accumulators of 8 rows in flight; uniform box: A / G = rings of the horizontally filtered rows
   // (of x / of the residual), Vs / Ws = the running vertical window sums
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
       constexpr int so = (J - LAG + 8) & 7;
       if (o >= r0 && o < r1) {
         if constexpr (((J - LAG + 8) & 3) == 0) {       // first row of a Philox quad (r0 % 8 == 0)
-          if (P.noise_mode == LMC_NOISE_PHILOX) {
+          if (!x_noise && P.noise_mode == LMC_NOISE_PHILOX) {
 #pragma unroll
             for (int k = 0; k < PXL; ++k) {
               float n4[4];
@@ -324,21 +331,21 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
               if constexpr (kNzLds) xi[q] = nzw[(jq * PXL + 4 * g + q) * 64];
               else xi[q] = nz[4 * g + q][jq];
             }
-            if (P.noise_mode == LMC_NOISE_INJECTED) rows_load4<AL>(xi, P.noise + (size_t)chain * img + go, c0 + 4 * g, W);
+            if (x_noise) rows_load4<AL>(xi, P.noise + (size_t)chain * img + go, c0 + 4 * g, W);
             float pe[4] = {0.f, 0.f, 0.f, 0.f}, ex[4] = {0.f, 0.f, 0.f, 0.f};
-            if (P.prox_ext) rows_load4<AL>(pe, P.prox_ext + (size_t)chain * img + go, c0 + 4 * g, W);
-            if (P.extra) rows_load4<AL>(ex, P.extra + (size_t)chain * img + go, c0 + 4 * g, W);
+            if (x_prox) rows_load4<AL>(pe, P.prox_ext + (size_t)chain * img + go, c0 + 4 * g, W);
+            if (x_extra) rows_load4<AL>(ex, P.extra + (size_t)chain * img + go, c0 + 4 * g, W);
             float ov[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const float x = xr[so][4 * g + q];
               float gr = UNI ? (P.sigma_f * cbox) * Ws[4 * g + q] : P.sigma_f * G[so][4 * g + q];
-              if (P.extra) gr = fmaf(P.extra_coef, x - ex[q], gr);
+              if (x_extra) gr = fmaf(P.extra_coef, x - ex[q], gr);
               float px = x;
               if constexpr (EP) px = eprox(P.eprox_kind, x, EproxParams{P.prior_p0, P.prior_p1});
               else if (P.prior_kind == LMC_PRIOR_L2) px = x * P.prior_p0;
               else if (P.prior_kind == LMC_PRIOR_L1) px = copysignf(fmaxf(fabsf(x) - P.prior_p0, 0.f), x);
-              if (P.prox_ext) px = pe[q];
+              if (x_prox) px = pe[q];
               ov[q] = fmaf(P.a, x, fmaf(-P.t, gr, fmaf(P.b, px, P.s * xi[q])));
               if constexpr (DOT) {
                 const bool mine = AL || (c0 + 4 * g + q >= st_lo && c0 + 4 * g + q < st_hi);
@@ -380,6 +387,18 @@ __global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step
       if (lane == 0) { unsafeAtomicAdd(&P.dot_out[2 * chain], tot); unsafeAtomicAdd(&P.dot_out[2 * chain + 1], tot2); }
     }
   }
+}
+
+#ifndef LMC_ROWS_X3_OFF7
+#define LMC_ROWS_X3_OFF7 0
+#endif
+template <int PXL, int KT, bool DOT = false, int ULO = -1, int UHI = -1, bool AL = true, bool EP = false>
+__global__ __launch_bounds__(256, (PXL == 8 || KT == 7) ? 2 : 3) void myula_step_rows_kernel(const StepArgs P, const int band_rows, const int nbands) {
+  __shared__ float nz_lds[PXL == 8 ? 4 * PXL * 4 * 64 : 1];
+  const int m = (P.noise_mode == LMC_NOISE_INJECTED ? 1 : 0) | (P.prox_ext ? 2 : 0) | (P.extra ? 4 : 0);      // uniform over the grid
+  if (m == 0) rows_body<PXL, KT, DOT, ULO, UHI, AL, EP, 0>(P, band_rows, nbands, nz_lds);
+  else if (!EP && !(LMC_ROWS_X3_OFF7 && PXL == 8 && KT == 7) && m == 3) rows_body<PXL, KT, DOT, ULO, UHI, AL, EP, EP ? -1 : 3>(P, band_rows, nbands, nz_lds);
+  else rows_body<PXL, KT, DOT, ULO, UHI, AL, EP, -1>(P, band_rows, nbands, nz_lds);
 }
 
 // Rank-1 factorisation h = u v^T of the blur taps (u: kh, v: kw).  Returns false if h is not separable.
