@@ -17,6 +17,12 @@
 
 namespace lmc {
 
+#ifndef LMC_RT_SPREAD
+#define LMC_RT_SPREAD 1
+#endif
+#ifndef LMC_RT_MAP_SPREAD
+#define LMC_RT_MAP_SPREAD 3
+#endif
 #ifndef LMC_WARM_MIN_WAVES
 #define LMC_WARM_MIN_WAVES 1
 #endif
@@ -300,18 +306,28 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
   // T2 + C | T3 + N.  In an RT launch the live stages are a prefix: a typical chain runs 3 to 5 of the 10 (waves T1, T2, half of T3), each with the
   // objective sums on top, the other T waves only pass the dual on, and the combine wave forms the objective of the iterate it returns.  A chain
   // with few live stages therefore pairs every heavy wave with a pass-through one: L + N | T1 + T4 | T2 + T3 | C + T5 (measured: DESIGN 3.0r).
+  // Which roles share a SIMD was searched exhaustively in round 3 (scripts/round3/perm_search.py: all 105 pairings, 512 x 512 x 1024; the role of hardware
+  // wave w is nibble w of the code): fixed K = 10: L + T2 | T1 + T3 | T4 + C | T5 + N 1.736 ms against 1.775 for the plain order and 2.07 for the worst
+  // (L + C or L + N with two TV waves together); per-chain exit with one live stage per wave: L + T3 | T1 + T5 | T2 + T4 | C + N 1.305 against 1.387.
   int wave = hw_wave;
+  if constexpr (K == 10 && !RT && !CHAIN) wave = ((KT == 7 ? 0x75264310u : 0x76325410u) >> (4 * hw_wave)) & 15;   // 7 taps: L + C | T1 + T2 | T3 + T5 | T4 + N (1.838 vs 1.875)
   if constexpr (RT && K == 10) {
 #ifndef LMC_RT_MAP
 #define LMC_RT_MAP 0
 #endif
-    if (kc <= 4) {
+    if (LMC_RT_SPREAD && LMC_RT_MAP_SPREAD >= 3 && kc <= NT) {
+      // one live stage per wave (t_role: spread)
+      wave = (0x74536210u >> (4 * hw_wave)) & 15;        // L + T3 | T1 + T5 | T2 + T4 | C + N
+    } else if (kc <= 4) {
       if (LMC_RT_MAP == 0) wave = hw_wave == 3 ? 6 : hw_wave == 4 ? 7 : hw_wave == 5 ? 4 : hw_wave == 6 ? 3 : hw_wave == 7 ? 5 : hw_wave;
       else if (LMC_RT_MAP == 1) wave = hw_wave == 4 ? 6 : hw_wave == 6 ? 4 : hw_wave;                                              // L + C | T1 + T5 | T2 + T4 | T3 + N
       else wave = hw_wave == 3 ? 6 : hw_wave == 4 ? 5 : hw_wave == 5 ? 4 : hw_wave == 6 ? 3 : hw_wave;                              // L + T5 | T1 + T4 | T2 + T3 | C + N
     }
     else wave = hw_wave == 4 ? 6 : hw_wave == 6 ? 4 : hw_wave;        // more live stages: L + C | T1 + T5 | T2 + T4 | T3 + N
   }
+#ifdef LMC_EXP_PERM   // timing experiment (scripts/round3/perm_search.py): role of hardware wave w = nibble w of A.PH (the tile kernel's field, unused here)
+  if (A.PH) wave = (A.PH >> (4 * hw_wave)) & 15;
+#endif
   // column strip of this workgroup (blockIdx.y; one strip = the whole row when W <= 64 PXL): c0 is a GLOBAL column, LDS rows are indexed by lane
   constexpr int HALO = pipe_halo(K, KT, PXL);
   const int strip = blockIdx.y;
@@ -556,9 +572,14 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     auto t_role = [&](auto first_tag, auto single_tag) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(first_tag)::value;      // stage k1 starts from the zero dual state
     constexpr bool SINGLE = decltype(single_tag)::value;    // odd K, last wave: stage k1 = K only, its output goes straight to the hand-off
-    const int k1 = 2 * wave - 1, k2 = 2 * wave;
+    const int k1 = 2 * wave - 1, k2 = 2 * wave;        // the wave's two SLOTS of the row schedule (rows a1, a2 below)
+    // RT, at most NT live stages (the chain the reference configures settles at 4): ONE live stage per wave -- slot k1 of wave j runs stage j, slot k2 only
+    // hands its state on -- instead of two stages each in the first waves and none in the rest: a wave's tick is then half as long, and what the others wait for at
+    // the barrier is no longer the two-stage waves' chain of hand-off reads, two stages and stores.  Same arithmetic on the same data: bit-identical.
+    const bool spread = RT && LMC_RT_SPREAD && kc <= NT;
+    const int g1 = spread ? wave : k1, g2 = k2;          // the STAGES the slots run (momentum coefficient, objective slot)
     const float gam = A.tv.gamma, cstep = A.tv.c;
-    const float beta1 = A.tv.betas[k1 - 1], beta2 = SINGLE ? 0.f : A.tv.betas[k2 - 1];
+    const float beta1 = A.tv.betas[g1 - 1], beta2 = SINGLE ? 0.f : A.tv.betas[g2 - 1];
     PipeCr<PXL / 2> crc;                                              // see PipeCr: AL kernels need W % PXL == 0 (host check), the others take any W
     crc.cstep = cstep;
     crc.cr_last = (c0 + PXL - 1 == W - 1) ? 0.f : cstep;
@@ -571,7 +592,8 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     constexpr int nof = warm ? 2 : 4;                                // fields per pixel of the outgoing state
     float* const sout = CHAIN && wave == NT && A.tv_out && (!RT || state_only) ? A.tv_out + (size_t)chain * nof * img : nullptr;
     constexpr int NP = PXL / 2;
-    const bool live1 = !RT || k1 <= kc, live2 = !RT || k2 <= kc;      // wave-uniform; live stages are a prefix: live2 implies live1
+    const bool live1 = !RT || g1 <= kc, live2 = !RT || (!spread && g2 <= kc);      // wave-uniform; live stages are a prefix
+    const bool fullpass2 = spread && wave < kc;          // a later wave still runs a live stage: slot k2 hands all four fields on, not (rr, ss) only
     ObjMask<NP> om;
     om.md = 0.f;
     om.mlast = v2f{1.f, (c0 + PXL - 1 == W - 1) ? 0.f : 1.f};
@@ -648,8 +670,12 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
         } else {                 // pass-through: the state of row a2 - 1 as stage k1 left it
 #pragma unroll
           for (int k = 0; k < NP; ++k) { out.rr[k] = o1[P].rr[k]; out.ss[k] = o1[P].ss[k]; }
+          if (fullpass2) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { out.p[k] = o1[P].p[k]; out.q[k] = o1[P].q[k]; }
+          }
         }
-        emit(out, P, a2 - 1, live2);
+        emit(out, P, a2 - 1, live2 || fullpass2);
       }
       {   // stage k1 on row a1: inputs from the previous wave's hand-off (row a1) and the one read a tick earlier (row a1-1)
         if constexpr (!FIRST) {
@@ -688,11 +714,11 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       double* const ob = A.rt_obj + (size_t)chain * A.rt_stride + A.rt_base;
       if (live1) {
         const double tot = wave_sum(0.5 * dg * dg * osq1 + dg * otv1);
-        if (lane == 0) unsafeAtomicAdd(ob + (k1 - 1), tot);
+        if (lane == 0) unsafeAtomicAdd(ob + (g1 - 1), tot);
       }
       if (!SINGLE && live2) {
         const double tot = wave_sum(0.5 * dg * dg * osq2 + dg * otv2);
-        if (lane == 0) unsafeAtomicAdd(ob + (k2 - 1), tot);
+        if (lane == 0) unsafeAtomicAdd(ob + (g2 - 1), tot);
       }
     }
     };   // t_role
@@ -940,6 +966,12 @@ static hipError_t pipe_launch_one(const StepArgs& a, hipStream_t st) {
   }
   const int BWk = 64 * PXL, U = BWk - 2 * pipe_halo(K, KT, PXL);
   const int nstrips = a.W <= BWk ? 1 : (a.W + U - 1) / U;       // wider than one wave: column strips with recomputed halos
+#ifdef LMC_EXP_PERM
+  StepArgs b = a;
+  if (const char* e = getenv("LMC_EXP_PERM")) b.PH = (int)strtoul(e, nullptr, 16);
+  hipLaunchKernelGGL(kern, dim3(a.C, nstrips), dim3(64 * ((K + 1) / 2 + 3)), lb, st, b);
+  return hipGetLastError();
+#endif
   hipLaunchKernelGGL(kern, dim3(a.C, nstrips), dim3(64 * ((K + 1) / 2 + 3)), lb, st, a);
   return hipGetLastError();
 }
