@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
   // with few live stages therefore pairs every heavy wave with a pass-through one: L + N | T1 + T4 | T2 + T3 | C + T5 (measured: DESIGN 3.0r).
   // Which roles share a SIMD was searched exhaustively in round 3 (scripts/round3/perm_search.py: all 105 pairings, 512 x 512 x 1024; the role of hardware
   // wave w is nibble w of the code): fixed K = 10: L + T2 | T1 + T3 | T4 + C | T5 + N 1.736 ms against 1.775 for the plain order and 2.07 for the worst
-  // (L + C or L + N with two TV waves together); per-chain exit with one live stage per wave: L + T3 | T1 + T5 | T2 + T4 | C + N 1.305 against 1.387.
+  // (L + C or L + N with two TV waves together); per-chain exit with one live stage per wave: by live count, below.
   int wave = hw_wave;
   if constexpr (K == 10 && !RT && !CHAIN) wave = ((KT == 7 ? 0x75264310u : 0x76325410u) >> (4 * hw_wave)) & 15;   // 7 taps: L + C | T1 + T2 | T3 + T5 | T4 + N (1.838 vs 1.875)
   if constexpr (RT && K == 10) {
@@ -317,7 +317,11 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
 #endif
     if (LMC_RT_SPREAD && LMC_RT_MAP_SPREAD >= 3 && kc <= NT) {
       // one live stage per wave (t_role: spread)
-      wave = (0x74536210u >> (4 * hw_wave)) & 15;        // L + T3 | T1 + T5 | T2 + T4 | C + N
+      // live TV waves beside L, N, C or a pass-through wave, never beside each other (searched on bench.py's data, where the chains settle at 4 passes -- 3 with
+      // the 7-tap models: 1.504 / 1.511 ms per iteration against 1.591 / 1.566 for the plain order; the best pairing for one live count is among the worst for another)
+      const unsigned code = kc >= 5 ? 0x76543210u : kc == 4 ? 0x67514320u      // kc = 4: L + T1 | T2 + T5 | T3 + N | T4 + C
+                                                              : 0x64753210u;     // kc <= 3: L + T5 | T1 + N | T2 + T4 | T3 + C
+      wave = (code >> (4 * hw_wave)) & 15;
     } else if (kc <= 4) {
       if (LMC_RT_MAP == 0) wave = hw_wave == 3 ? 6 : hw_wave == 4 ? 7 : hw_wave == 5 ? 4 : hw_wave == 6 ? 3 : hw_wave == 7 ? 5 : hw_wave;
       else if (LMC_RT_MAP == 1) wave = hw_wave == 4 ? 6 : hw_wave == 6 ? 4 : hw_wave;                                              // L + C | T1 + T5 | T2 + T4 | T3 + N

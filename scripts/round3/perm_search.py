@@ -12,7 +12,8 @@ args = ap.parse_args()
 H = W = 512; C = 1024; sigma = 0.75
 rng = np.random.default_rng(0)
 k = args.k
-img = rng.uniform(0, 255, (H, W)); h = np.ones((k, k)) / k ** 2
+from bench import synth_problem          # bench.py's own data: the exit pass of the TV prox (4 on it) decides which waves are live
+_, h, img = synth_problem(H, W, sigma, 0, "box", k)
 Hop = la.Convolve2D((H, W), h, offset=(k // 2, k // 2))
 f = la.L2(Op=Hop, b=img.ravel(), sigma=1 / sigma ** 2)
 if args.mc:
@@ -43,4 +44,8 @@ res.sort()
 for ms, name, code in res: print(f"{ms:7.4f} ms  {name}   {code}")
 os.environ["LMC_EXP_PERM"] = "0"
 smp.step(2); print(f"{timed():7.4f} ms  (the library's own order)")
+if args.rtol and not args.me:
+    import ctypes as C
+    ps = torch.zeros(1024, dtype=torch.int32, device="cuda"); rr = (C.c_uint64 * 4)()
+    print("exit passes of the last iteration:", np.bincount(smp.tv_exit_stats()[0].cpu().numpy(), minlength=11).tolist() if hasattr(smp, "tv_exit_stats") else "?")
 smp.close()
