@@ -310,7 +310,10 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
   // wave w is nibble w of the code): fixed K = 10: L + T2 | T1 + T3 | T4 + C | T5 + N 1.736 ms against 1.775 for the plain order and 2.07 for the worst
   // (L + C or L + N with two TV waves together); per-chain exit with one live stage per wave: by live count, below.
   int wave = hw_wave;
-  if constexpr (K == 10 && !RT && !CHAIN) wave = ((KT == 7 ? 0x75264310u : 0x76325410u) >> (4 * hw_wave)) & 15;   // 7 taps: L + C | T1 + T2 | T3 + T5 | T4 + N (1.838 vs 1.875)
+  if constexpr (K == 10 && !RT && !CHAIN) {   // 7 taps: L + C | T1 + T2 | T3 + T5 | T4 + N (1.838 vs 1.875); with the MC-TV term in the combine wave: L + T5 | T1 + T3 | T2 + C | T4 + N (1.962 vs 1.983)
+    const unsigned code = A.ncvx_kind == LMC_NCVX_MC_TV ? 0x76354210u : (KT == 7 ? 0x75264310u : 0x76325410u);
+    wave = (code >> (4 * hw_wave)) & 15;
+  }
   if constexpr (RT && K == 10) {
 #ifndef LMC_RT_MAP
 #define LMC_RT_MAP 0
