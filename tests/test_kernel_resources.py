@@ -63,3 +63,14 @@ def test_kernels_of_the_reference_models_use_no_scratch(resources):
         assert hits, f"no kernel matches {prefix}"
         bad += [(r["demangled"], r["scratch"]) for r in hits if r["scratch"] > 0]
     assert not bad, f"kernels on the reference's model paths that spill to scratch: {bad}"
+
+
+def test_role_pairing_codes_are_permutations():
+    """The pipe kernel assigns its eight roles to hardware waves by 8-nibble codes (nibble w = role of hardware wave w; waves w and w + 4 share a
+    SIMD): every code in the kernel source must name each role exactly once -- a repeated role would leave another one without a wave."""
+    import re
+    src = open(os.path.join(ROOT, "lmc_atomi_amd", "csrc", "lmc_step_pipe_kernel.h")).read()
+    codes = re.findall(r"0x([0-9a-fA-F]{8})u", src)
+    assert len(codes) >= 5
+    for c in codes:
+        assert sorted(int(ch, 16) for ch in c) == list(range(8)), c
