@@ -99,6 +99,9 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
   float wr[MC ? 2 : 1][MC ? 10 : 1], vxp[MC ? 8 : 1], vxc[MC ? 9 : 1], vyc[MC ? 9 : 1];
   const int gi0 = by * 8, gj0 = bx * 8;
   const float* __restrict__ ximg = P.x_in + (size_t)chain * img;
+  // 512 columns = 64 blocks = exactly one wave per block row (and every wave is full: blocks_per_img is a multiple of 64): the one-pixel column halo of the
+  // MC-TV window comes from the neighbouring lanes instead of memory (round 3: traffic 1.51 -> see DESIGN 3.0b)
+  const bool row_in_wave = MC && nbx == 64;
   auto load_wrow = [&](float (&d)[MC ? 10 : 1], int rr) {      // rr: block-local row -1 .. 8
     if constexpr (MC) {
       const int gi = min(max(gi0 + rr, 0), H - 1);
@@ -110,8 +113,13 @@ __global__ __launch_bounds__(256, LMC_BLK_OCC) void myula_step_block_kernel(cons
         const float4 lo = *reinterpret_cast<const float4*>(row + gj0), hi = *reinterpret_cast<const float4*>(row + gj0 + 4);
         d[1] = lo.x; d[2] = lo.y; d[3] = lo.z; d[4] = lo.w; d[5] = hi.x; d[6] = hi.y; d[7] = hi.z; d[8] = hi.w;
       }
-      d[0] = row[max(gj0 - 1, 0)];
-      d[9] = row[min(gj0 + 8, W - 1)];
+      if (row_in_wave) {        // the blocks left and right of this one belong to the neighbouring lanes: their edge pixels by a wave shift (lane 0 / 63 sit
+        d[0] = dpp_left0(d[8]);   // at the image edge, where the has-neighbour flags of v_row void the value)
+        d[9] = dpp_right0(d[1]);
+      } else {                   // two strided dword loads per window row: 64 sectors touched for 256 useful bytes each
+        d[0] = row[max(gj0 - 1, 0)];
+        d[9] = row[min(gj0 + 8, W - 1)];
+      }
     }
   };
   // (vx, vy) of block row rr (-1 .. 7) from window rows `cu` (row rr) and `dn` (row rr + 1): columns m - 1 for m = 0 .. 8

@@ -138,6 +138,38 @@ def test_haar_prior_many_iterations_philox_and_moments(la):
         s.close()
 
 
+def test_config5_mc_term_at_512_columns_column_halo_from_the_neighbouring_lanes(la):
+    """At W = 512 a wave is exactly one row of 8 x 8 blocks and the block kernel takes the column halo of the MC-TV window from the neighbouring lanes
+    (wave shifts) instead of memory: the same step against the checker's class gradient, image edges and block seams included."""
+    shape = (24, 512)
+    sigma, lam = 0.75, 0.3
+    gamma, tau = sigma ** 2, 0.2 * sigma ** 2
+    mask = (np.random.default_rng(7).uniform(size=shape) < 0.5).astype(np.float64)
+    rng = np.random.default_rng(3)
+    img = np.zeros(shape); img[4:18, 100:400] = 200.0
+    img += np.linspace(0, 40, shape[1])[None, :]
+    y = mask * (img + rng.normal(0, sigma, shape))
+    C, nit = 3, 3
+    x0 = img[None] + rng.normal(0, 12, (C,) + shape)
+    noise = rng.standard_normal((nit, C) + shape)
+    kw = dict(dims=shape, b=y.ravel(), sigma=1 / sigma ** 2, lamda=0.3, gamma=15.0, isotropic=True, niter=1)
+    pf = la.L2_ncvx_tv(Op=la.Diagonal(mask, dims=shape), Op2=la.Gradient(shape), **kw)
+    of = O.L2NcvxTV(Op=O.Diagonal(mask), Op2=O.Gradient(shape), **kw)
+    pg = la.WaveletL1(shape, sigma=lam)
+    smp = la.MYULASampler(pf, pg, shape, n_chains=C, tau=tau, gamma=gamma, noise="injected")
+    smp.set_state(x0)
+    x = x0.copy()
+    for it in range(nit):
+        smp.step(1, noise=noise[it:it + 1])
+        assert "block" in smp.kernel_name, smp.kernel_name
+        g = np.stack([of.grad(x[c].ravel().copy()).reshape(shape) for c in range(C)])
+        x = (1 - tau / gamma) * x - tau * g + (tau / gamma) * O.haar_l1_prox(x, gamma * lam) + np.sqrt(2 * tau) * noise[it]
+        got = smp.get_state().cpu().numpy()
+        err = np.abs(got - x).max(axis=(0, 1))          # per column: a wrong halo shows at the block seams
+        assert rel(got, x) < 5e-6 * (it + 1) and err.max() < 2e-3, (it, rel(got, x), int(err.argmax()), err.max())
+    smp.close()
+
+
 @pytest.mark.parametrize("kind,niter_in", [("mc", 0), ("me", 8), ("me", 30)])
 def test_config5_mask_haar_with_nonconvex_term(la, kind, niter_in):
     """Bernoulli(0.5) mask from default_rng(7), Haar-l1 prox (threshold 0.3*gamma) and the L2_ncvx_tv-style
