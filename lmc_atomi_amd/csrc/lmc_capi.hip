@@ -1962,6 +1962,7 @@ int lmc_ulpda_create(const lmc_ulpda_config* cfg, lmc_sampler** out) {
   if (s->prob.ncvx_kind == LMC_NCVX_ME_TV) {
     alloc(&s->extra, n);
     if (needs_tv_state(s->prob)) { alloc(&s->tvstate[0], 4 * n); alloc(&s->tvstate[1], 4 * n); }
+    if (e == hipSuccess && s->prob.ncvx_rtol > 0.f) e = s->rt_me.need((size_t)s->C, s->prob.ncvx_niter);     // early exit of the inner prox, decided on the device
   }
   if (e == hipSuccess && s->moments) {
     const size_t mb = sizeof(double) * img;

@@ -193,3 +193,26 @@ def test_me_tv_inner_prox_leaves_where_the_checkers_does(la, shape, niter):
         np.testing.assert_array_equal(ps.cpu().numpy(), passes)
         assert reruns[3] == 0
         smp.close()
+
+
+@pytest.mark.parametrize("shape", [(24, 136), (20, 96)])
+def test_ulpda_with_the_me_tv_term_as_the_reference_configures_it(la, shape):
+    """ULPDA whose data term carries the ME-TV term with the class's own rtol = 1e-4 (what `python -m lmc_atomi_amd.deconv` runs by default for
+    models M3 / M6 / M9; prox_lmc_deconv.py:111-113, 478-487): the pre-step's inner prox leaves where the checker's does (136 columns: decided on the device;
+    96: pass by pass).  Found missing in round 3: the ULPDA sampler did not allocate the early-exit state."""
+    rng = np.random.default_rng(21)
+    img = np.zeros(shape); img[5:16, 20:70] = 170.0
+    img += np.linspace(0, 30, shape[1])[None, :]
+    h = np.ones((5, 5)) / 25
+    y = O.blur(img, h, (2, 2)) + rng.normal(0, SIGMA, shape)
+    n = shape[0] * shape[1]
+    nit = 4
+    tau0, mu0 = 0.95 * SIGMA ** 2, 0.99 / (0.95 * SIGMA ** 2 * 8)
+    kw = dict(dims=shape, b=y.ravel(), sigma=1 / SIGMA ** 2, lamda=0.3, gamma=15.0, isotropic=True, niter=50)
+    for rtol in (1e-4, 0.0):
+        pf = la.L2_ncvx_tv(Op=la.Convolve2D(shape, h, offset=(2, 2)), warm=True, rtol=rtol, **kw)
+        of = O.L2NcvxTV(Op=O.Convolve2D(shape, h, (2, 2)), tv_kwargs={"rtol": rtol}, **kw)
+        xs = la.UnadjustedLangevinPrimalDual(pf, la.L21(ndim=2, sigma=0.3), la.Gradient(shape), tau=tau0, mu=mu0, theta=1.0, x0=np.zeros(n), gfirst=False,
+                                             niter=nit, seed=4, rng="pcg64")
+        ref = O.ulpda(of, O.L21(ndim=2, sigma=0.3), O.Gradient(shape), np.zeros(n), tau0, mu0, theta=1.0, niter=nit, seed=4, gfirst=False)
+        assert rel(xs, ref) < 2e-4, (rtol, rel(xs, ref))
