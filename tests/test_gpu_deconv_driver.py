@@ -28,6 +28,19 @@ def test_nine_models_both_samplers_small():
     assert res1["M1"]["mean"].shape == img.shape
 
 
+@pytest.mark.parametrize("alg", ["MYULA", "ULPDA", "MYMALA"])
+def test_nine_models_at_a_width_the_fused_kernels_cover(alg):
+    """The same driver at 264 columns, where the full-width pipeline and the device-side early exit of the TV proxes run (the 64-column case above takes the
+    general kernels and the pass-by-pass exit): every model with the driver's defaults (rtol = 1e-4, niter_l2 = 50), as `python -m lmc_atomi_amd.deconv` runs them."""
+    import torch
+    assert torch.cuda.is_available()
+    from lmc_atomi_amd.deconv import prox_lmc_deconv, synthetic_image
+    img = synthetic_image(40, 264)
+    res = prox_lmc_deconv(N=12, image=img, alg=alg, seed=0, n_chains=3, burn_in=4, thin=1, verbose=False)
+    for m in ("M1", "M2", "M3", "M4", "M5", "M6", "M7", "M8", "M9"):
+        assert res[m]["mean"].shape == img.shape and np.all(np.isfinite(res[m]["mean"])), (alg, m)
+
+
 def test_driver_mymala_branch():
     """--alg MYMALA: the Metropolis-adjusted sampler through the same driver (three models incl. both L2_ncvx_tv terms)."""
     import torch
