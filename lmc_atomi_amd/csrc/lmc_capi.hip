@@ -397,6 +397,19 @@ hipError_t launch_step(const lmc::StepArgs& A_in, int variant, hipStream_t st, c
   if (v == 7) return hipErrorInvalidConfiguration;
   // auto: split pipeline when it covers the configuration (W <= 512); for wider images the tiled kernels:
   // "point" for closed-form priors with a separable blur, else the general LDS-tiled kernel
+  // a closed-form elementwise prior (LMC_PRIOR_EPROX) that reaches this point (a non-log-concave term, or a blur the row kernel does not cover): the split and
+  // tiled kernels have no functor for it -- the point kernel evaluates it in place; where that does not cover the data term the prox is formed by one elementwise
+  // launch and consumed as a ready-made prox.  (Round 3's configuration-matrix test found these combinations running with prox = identity.)
+  if (A.prior_kind == LMC_PRIOR_EPROX) {
+    if ((v == 0 || v == 4) && lmc::point_supported(A)) v = 4;
+    else {
+      if (!pxbuf) return hipErrorInvalidConfiguration;
+      hipError_t e = lmc::launch_eprox(A.eprox_kind, A.x_in, pxbuf, (int64_t)A.C * A.H * A.W, A.prior_p0, A.prior_p1, st);
+      if (e != hipSuccess) return e;
+      A.prior_kind = LMC_PRIOR_NONE;
+      A.prox_ext = pxbuf;
+    }
+  }
   if (v == 0) v = lmc::split_supported(A) ? 3 : (lmc::point_supported(A) ? 4 : 1);
   if (v == 4) {
     if (!lmc::point_supported(A)) return hipErrorInvalidConfiguration;
@@ -1007,7 +1020,7 @@ int lmc_fused_eval(const lmc_problem* prob, const float* x_dev, float* out_dev, 
     A.extra = g_scratch.extra;
     A.extra_coef = -q.ncvx_lambda / q.ncvx_gamma;
   }
-  if (A.prior_kind == LMC_PRIOR_HAAR_L1) HIP_TRY(g_scratch.need_prox(npx));
+  if (A.prior_kind == LMC_PRIOR_HAAR_L1 || A.prior_kind == LMC_PRIOR_EPROX) HIP_TRY(g_scratch.need_prox(npx));
   if (A.prior_kind == LMC_PRIOR_TV_ISO && q.tv_rtol > 0.f && tv_prior_rt_mode(q, A, pt) != 2) {     // the early exit decided on the device
     Scratch& sc = g_scratch;
     HIP_TRY(sc.need_prox(npx));
@@ -1206,7 +1219,7 @@ int lmc_myula_create(const lmc_myula_config* cfg, lmc_sampler** out) {
     if (e == hipSuccess) e = hipMalloc(&s->tvstate[1], 4 * nbytes);
   }
   if (e == hipSuccess && s->prob.ncvx_kind == LMC_NCVX_ME_TV) e = hipMalloc(&s->extra, nbytes);
-  if (e == hipSuccess && (s->prob.prior_kind == LMC_PRIOR_HAAR_L1 || s->prob.prox_scale)) e = hipMalloc(&s->pxbuf, nbytes);
+  if (e == hipSuccess && (s->prob.prior_kind == LMC_PRIOR_HAAR_L1 || s->prob.prior_kind == LMC_PRIOR_EPROX || s->prob.prox_scale)) e = hipMalloc(&s->pxbuf, nbytes);
   if (e == hipSuccess && s->prob.tv_rtol > 0.f && s->base.prior_kind == LMC_PRIOR_TV_ISO) {
     if (s->prob.tv_warm) { lmc_sampler_destroy(s); return fail(LMC_E_UNSUPPORTED, "tv_rtol > 0 and tv_warm exclude each other"); }
     const int mode = tv_prior_rt_mode(s->prob, s->base, s->epsg * s->gamma);     // 1: inside the fused launch, 0: prox alone, 2: pass by pass

@@ -485,8 +485,9 @@ class L2_ncvx_tv(ProxOperator):
             raise NotImplementedError("q (linear term) has no device functor")
         if Op2 is not None and not isinstance(Op2, Gradient):
             raise NotImplementedError("Op2 must be a Gradient (MC-TV) or None (ME-TV)")
-        if not isinstance(Op, (Convolve2D, Diagonal)) or b is None:
-            raise NotImplementedError("Op must be a Convolve2D (prox_lmc_deconv.py:106) or a Diagonal mask, and b given")
+        from .operators import Identity
+        if not isinstance(Op, (Convolve2D, Diagonal, Identity)) or b is None:
+            raise NotImplementedError("Op must be a Convolve2D (prox_lmc_deconv.py:106), a Diagonal mask or an Identity, and b given")
         self.dims = (int(dims[0]), int(dims[1]))
         self.Op2 = Op2
         self.b = b
@@ -503,6 +504,8 @@ class L2_ncvx_tv(ProxOperator):
     def descriptor(self):
         if isinstance(self.Op, Diagonal):
             base = {"data_kind": _capi.DATA_MASK, "sigma_f": self.sigma, "y": self.b, "mask": self.Op.d}
+        elif not isinstance(self.Op, Convolve2D):     # Identity (denoising)
+            base = {"data_kind": _capi.DATA_IDENTITY, "sigma_f": self.sigma, "y": self.b}
         else:
             base = {"data_kind": _capi.DATA_BLUR, "sigma_f": self.sigma, "y": self.b, "h": self.Op.h, "offset": self.Op.offset}
         if self.Op2 is None:       # ME-TV: isotropic (2-D TV, algs.py:169) or the 1-D TV of the flattened image (algs.py:170)

@@ -1,0 +1,106 @@
+"""A matrix of configurations -- image widths that select every step kernel (tiled / split / rows / block / point / pipe / strips), data terms (blur 5 and
+7 taps, identity, mask), priors (TV fixed count and with upstream's early exit, l2, l1, Haar-l1, a closed form of prox.py) and the non-log-concave terms
+of L2_ncvx_tv (MC-TV, ME-TV with its rtol) -- each run for three MYULA iterations on three chains with injected noise against the CPU checker's
+class-based loop.  The single-feature suites test each kernel in depth; this one looks for holes BETWEEN features (round 3 found one by running the driver
+end to end: the ULPDA sampler without the early-exit state of the ME-TV prox)."""
+import itertools
+
+import numpy as np
+import pytest
+
+from oracle import lmc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SIG = 0.75
+GAM, TAU = SIG ** 2, 0.2 * SIG ** 2
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+    assert torch.cuda.is_available()
+    import lmc_atomi_amd as la
+    return la
+
+
+SHAPES = [(16, 64), (24, 136), (16, 264), (16, 512), (8, 528)]
+DATA = ["blur5", "blur7", "identity", "mask"]
+PRIORS = ["tv", "tv_rtol", "l2", "l1", "haar", "laplace"]
+NCVX = ["none", "mc", "me"]
+
+
+def build(la, shape, data, prior, ncvx, rng):
+    n = shape[0] * shape[1]
+    img = np.zeros(shape); img[3:shape[0] - 4, shape[1] // 8:shape[1] // 2] = 150.0
+    img += np.linspace(0, 30, shape[1])[None, :]
+    if data.startswith("blur"):
+        k = int(data[4:])
+        h = np.ones((k, k)) / k ** 2
+        y = O.blur(img, np.ones((5, 5)) / 25, (2, 2)) + rng.normal(0, SIG, shape)
+        Op, oOp = la.Convolve2D(shape, h, offset=(k // 2, k // 2)), O.Convolve2D(shape, h, (k // 2, k // 2))
+    elif data == "identity":
+        y = img + rng.normal(0, SIG, shape)
+        Op, oOp = None, None
+    else:
+        m = (rng.uniform(size=shape) < 0.5).astype(np.float64)
+        y = m * (img + rng.normal(0, SIG, shape))
+        Op, oOp = la.Diagonal(m, dims=shape), O.Diagonal(m)
+    if ncvx == "none":
+        f, of = la.L2(Op=Op, b=y.ravel(), sigma=1 / SIG ** 2), O.L2(Op=oOp, b=y.ravel(), sigma=1 / SIG ** 2)
+    else:
+        kw = dict(dims=shape, b=y.ravel(), sigma=1 / SIG ** 2, lamda=0.3, gamma=15.0, isotropic=True, niter=20)
+        if Op is None:
+            Op, oOp = la.Identity(n), O.Identity(n)
+        if ncvx == "mc":
+            f, of = la.L2_ncvx_tv(Op=Op, Op2=la.Gradient(shape), **kw), O.L2NcvxTV(Op=oOp, Op2=O.Gradient(shape), **kw)
+        else:
+            f, of = la.L2_ncvx_tv(Op=Op, rtol=1e-4, **kw), O.L2NcvxTV(Op=oOp, tv_kwargs={"rtol": 1e-4}, **kw)
+    if prior == "tv":
+        g, og = la.TV(shape, sigma=0.3, niter=10), O.TV(shape, sigma=0.3, niter=10)
+    elif prior == "tv_rtol":
+        g, og = la.TV(shape, sigma=0.3, niter=10, rtol=1e-4), O.TV(shape, sigma=0.3, niter=10, rtol=1e-4)
+    elif prior == "l2":
+        g, og = la.L2(sigma=0.05), O.L2(sigma=0.05)
+    elif prior == "l1":
+        g, og = la.L1(sigma=0.8), O.L1(sigma=0.8)
+    elif prior == "haar":
+        g, og = la.WaveletL1(shape, sigma=0.3), O.WaveletL1(shape, sigma=0.3)
+    else:
+        class _Lap:
+            def prox(self, x, t): return O.prox_laplace(x, t * 1.5)
+        g, og = la.Laplace(1.5), _Lap()
+    return img, f, of, g, og
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_every_combination_of_data_term_prior_and_nonconvex_term(la, shape):
+    rng = np.random.default_rng(shape[1])
+    C_, nit = 3, 3
+    bad = []
+    for data, prior, ncvx in itertools.product(DATA, PRIORS, NCVX):
+        if prior == "haar" and (shape[0] % 8 or shape[1] % 8):
+            continue
+        img, f, of, g, og = build(la, shape, data, prior, ncvx, rng)
+        x0 = img[None] + rng.normal(0, [[[3.0]], [[10.0]], [[25.0]]], (C_,) + shape)
+        noise = rng.standard_normal((nit, C_) + shape)
+        try:
+            smp = la.MYULASampler(f, g, shape, n_chains=C_, tau=TAU, gamma=GAM, noise="injected")
+        except NotImplementedError:
+            continue
+        smp.set_state(x0)
+        smp.step(nit, noise=noise)
+        got = smp.get_state().cpu().numpy()
+        name = smp.kernel_name
+        smp.close()
+        ref = np.stack([O.myula(of, og, x0[c].ravel(), TAU, GAM, niter=nit, noise=[noise[i, c].ravel() for i in range(nit)])[-1].reshape(shape) for c in range(C_)])
+        e = rel(got, ref)
+        if not (e < 5e-5):
+            bad.append((data, prior, ncvx, name, e))
+    assert not bad, "\n".join(f"{d} {p} {n} {k} {e:.2e}" for d, p, n, k, e in bad)
