@@ -104,3 +104,40 @@ def test_every_combination_of_data_term_prior_and_nonconvex_term(la, shape):
         if not (e < 5e-5):
             bad.append((data, prior, ncvx, name, e))
     assert not bad, "\n".join(f"{d} {p} {n} {k} {e:.2e}" for d, p, n, k, e in bad)
+
+
+@pytest.mark.parametrize("shape", [(16, 64), (24, 136), (16, 264), (8, 528)])
+def test_ulpda_every_data_term_nonconvex_term_and_dual_prox(la, shape):
+    """The same for ULPDA (algs.py:295-474): data term (blur 5 / 7 taps, identity, mask) x non-log-concave term (none, MC-TV, ME-TV with its rtol) x dual prox
+    (L21 = isotropic TV, L1 = anisotropic), both orders of the primal and dual step, three chains with injected noise against the checker's loop (whose
+    implicit step is 50 CG iterations: 2e-4)."""
+    rng = np.random.default_rng(shape[1] + 1)
+    C_, nit = 2, 3
+    n = shape[0] * shape[1]
+    tau0 = 0.95 * SIG ** 2
+    mu0 = 0.99 / (tau0 * 8)
+    bad = []
+    for data, ncvx, iso, gfirst in itertools.product(DATA, NCVX, (True, False), (False, True)):
+        if gfirst and (ncvx != "none" or not iso):
+            continue                                   # the other order: once per data term is enough
+        img, f, of, _, _ = build(la, shape, data, "l2", ncvx, rng)
+        g, og = (la.L21(ndim=2, sigma=0.3), O.L21(ndim=2, sigma=0.3)) if iso else (la.L1(sigma=0.3), O.L1(sigma=0.3))
+        x0 = img[None] + rng.normal(0, [[[3.0]], [[12.0]]], (C_,) + shape)
+        noise = rng.standard_normal((nit, C_) + shape)
+        try:
+            smp = la.ULPDASampler(f, g, la.Gradient(shape), shape, n_chains=C_, tau=tau0, mu=mu0, theta=1.0, gfirst=gfirst, noise="injected")
+        except NotImplementedError:
+            continue
+        except la.LMCError as err:                    # refused loudly (LMC_E_UNSUPPORTED): the non-convex terms of ULPDA are built for the blur data term
+            assert err.code == -2 and data in ("identity", "mask") and ncvx != "none", (data, ncvx, err)
+            continue
+        smp.set_state(x0)
+        smp.step(nit, noise=noise)
+        got = smp.get_state().cpu().numpy()
+        smp.close()
+        ref = np.stack([O.ulpda(of, og, O.Gradient(shape), x0[c].ravel(), tau0, mu0, theta=1.0, niter=nit, gfirst=gfirst,
+                                noise=[noise[i, c].ravel() for i in range(nit)])[-1].reshape(shape) for c in range(C_)])
+        e = rel(got, ref)
+        if not (e < 2e-4):
+            bad.append((data, ncvx, "L21" if iso else "L1", f"gfirst={gfirst}", e))
+    assert not bad, "\n".join(f"{d} {p} {n_} {k} {e:.2e}" for d, p, n_, k, e in bad)
