@@ -1109,7 +1109,24 @@ int lmc_l2_prox(const lmc_problem* prob, const float* x_dev, float* out_dev, int
   const float ts = tau * q.sigma_f;
   const size_t n = (size_t)n_img * q.H * q.W;
   if (q.data_kind != LMC_DATA_BLUR) {
-    HIP_TRY(lmc::ulpda_pointwise_prox(x_dev, out_dev, q.y, q.mask, n_img, q.H, q.W, ts, q.data_kind, st));
+    const float* xin = x_dev;
+    if (q.ncvx_kind != LMC_NCVX_NONE && q.data_kind != LMC_DATA_NONE) {
+      // L2_ncvx_tv.prox with a pointwise data term: the pre-step of algs.py:213-223 first (x + tau lambda A^T(Ax / max(|Ax|, gamma)), or
+      // x + tau lambda / gamma (x - prox_{gamma TV}(x))), then the closed-form solve.  (Round 3's matrix test found this path applying the solve to x itself.)
+      HIP_TRY(g_scratch.need_prox(n));
+      if (q.ncvx_kind == LMC_NCVX_MC_TV) {
+        HIP_TRY(lmc::ulpda_ncvx_rhs(x_dev, q.y, g_scratch.prox, n_img, q.H, q.W, tau * q.ncvx_lambda, q.ncvx_gamma, 0.f, st));     // ts = 0: the H^T b slot adds nothing
+      } else {
+        HIP_TRY(g_scratch.need_extra(n));
+        if (needs_tv_state(q)) HIP_TRY(g_scratch.need_state(4 * n));
+        if (q.ncvx_rtol > 0.f) HIP_TRY(g_scratch.rt_me.need((size_t)n_img, q.ncvx_niter));
+        rc = me_tv_prox(q, x_dev, g_scratch.extra, n_img, g_scratch.state[0], g_scratch.state[1], st, &g_scratch.rt_me);
+        if (rc) return rc;
+        HIP_TRY(lmc::ulpda_me_rhs(x_dev, g_scratch.extra, q.y, g_scratch.prox, n_img, q.H, q.W, tau * q.ncvx_lambda / q.ncvx_gamma, 0.f, st));
+      }
+      xin = g_scratch.prox;
+    }
+    HIP_TRY(lmc::ulpda_pointwise_prox(xin, out_dev, q.y, q.mask, n_img, q.H, q.W, ts, q.data_kind, st));
     return LMC_OK;
   }
   if (niter < 1) return fail(LMC_E_INVALID, "niter must be >= 1");
@@ -1852,17 +1869,20 @@ static int ulpda_step(lmc_sampler* s, int32_t n_iters, const float* noise_dev, h
   for (int k = 0; k < n_iters; ++k) {
     float* x = s->x[s->cur];
     const float ts = s->tau * s->prob.sigma_f;
+    // pre-step of L2_ncvx_tv.prox: with a blur the right-hand side also takes tau sigma H^T b; the pointwise solves add their tau sigma m b themselves
+    const float* htb_nc = s->prob.data_kind == LMC_DATA_BLUR ? s->htb : s->prob.y;
+    const float ts_nc = s->prob.data_kind == LMC_DATA_BLUR ? ts : 0.f;
     if (s->gfirst)   // y <- proxdual(y + mu A xhat)   (algs.py:436)
       HIP_TRY(lmc::ulpda_dual_update(s->xhat, s->ydual, C, H, W, s->mu, s->prob.prior_sigma, iso, st));
     // v = x - tau (A^T y + z) [+ tau sigma H^T b]      (algs.py:437-440 / 443-446)
     if (s->prob.ncvx_kind == LMC_NCVX_MC_TV) {   // L2_ncvx_tv.prox pre-step (algs.py:213-217), then + tau sigma H^T b (:225)
       HIP_TRY(lmc::ulpda_rhs(x, s->ydual, s->z, nullptr, s->ctmp, C, H, W, s->tau, ts, st));
-      HIP_TRY(lmc::ulpda_ncvx_rhs(s->ctmp, s->htb, s->rhs, C, H, W, s->tau * s->prob.ncvx_lambda, s->prob.ncvx_gamma, ts, st));
+      HIP_TRY(lmc::ulpda_ncvx_rhs(s->ctmp, htb_nc, s->rhs, C, H, W, s->tau * s->prob.ncvx_lambda, s->prob.ncvx_gamma, ts_nc, st));
     } else if (s->prob.ncvx_kind == LMC_NCVX_ME_TV) {   // x += tau*lamda/gamma (x - prox_{gamma TV}(x))  (algs.py:221-223)
       HIP_TRY(lmc::ulpda_rhs(x, s->ydual, s->z, nullptr, s->ctmp, C, H, W, s->tau, ts, st));
       int rc = me_tv_prox(s->prob, s->ctmp, s->extra, C, s->tvstate[0], s->tvstate[1], st, &s->rt_me);
       if (rc) return rc;
-      HIP_TRY(lmc::ulpda_me_rhs(s->ctmp, s->extra, s->htb, s->rhs, C, H, W, s->tau * s->prob.ncvx_lambda / s->prob.ncvx_gamma, ts, st));
+      HIP_TRY(lmc::ulpda_me_rhs(s->ctmp, s->extra, htb_nc, s->rhs, C, H, W, s->tau * s->prob.ncvx_lambda / s->prob.ncvx_gamma, ts_nc, st));
     } else if (s->rhs_ready && s->rhs_tau == s->tau && s->rhs_ts == ts) {
       // formed together with the previous iteration's dual update (fuse_dr below)
     } else
@@ -1935,8 +1955,8 @@ int lmc_ulpda_create(const lmc_ulpda_config* cfg, lmc_sampler** out) {
     return fail(LMC_E_UNSUPPORTED, "ULPDA needs g o A with g = L21 (LMC_PRIOR_TV_ISO) or L1 (LMC_PRIOR_TV_ANISO)");
   if (!(cfg->problem.prior_sigma > 0.f)) return fail(LMC_E_INVALID, "prior_sigma (dual ball radius) must be > 0");
   if (cfg->problem.data_kind == LMC_DATA_BLUR && cfg->cg_niter < 1) return fail(LMC_E_INVALID, "cg_niter must be >= 1");
-  if (cfg->problem.ncvx_kind != LMC_NCVX_NONE && cfg->problem.data_kind != LMC_DATA_BLUR)
-    return fail(LMC_E_UNSUPPORTED, "the non-convex term is built for the blur data term only (prox_lmc_deconv.py:106)");
+  if (cfg->problem.ncvx_kind != LMC_NCVX_NONE && cfg->problem.data_kind == LMC_DATA_NONE)
+    return fail(LMC_E_UNSUPPORTED, "the non-convex term belongs to a data term (blur, identity or mask)");
   lmc_sampler* s = new (std::nothrow) lmc_sampler();
   if (!s) return fail(LMC_E_NOMEM, "host allocation failed");
   lmc_problem pr = cfg->problem;
@@ -1972,6 +1992,7 @@ int lmc_ulpda_create(const lmc_ulpda_config* cfg, lmc_sampler** out) {
     if (e == hipSuccess) e = lmc::launch_blur(s->prob.y, s->htb, 1, s->prob.H, s->prob.W, s->prob.taps, 1, nullptr);   // H^T b
     if (e == hipSuccess) e = hipDeviceSynchronize();
   }
+  if (s->prob.ncvx_kind != LMC_NCVX_NONE && !s->ctmp) alloc(&s->ctmp, n);      // pointwise data terms: the pre-step of L2_ncvx_tv.prox needs its own array
   if (s->prob.ncvx_kind == LMC_NCVX_ME_TV) {
     alloc(&s->extra, n);
     if (needs_tv_state(s->prob)) { alloc(&s->tvstate[0], 4 * n); alloc(&s->tvstate[1], 4 * n); }
