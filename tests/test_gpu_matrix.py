@@ -103,6 +103,19 @@ def test_every_combination_of_data_term_prior_and_nonconvex_term(la, shape):
         e = rel(got, ref)
         if not (e < 5e-5):
             bad.append((data, prior, ncvx, name, e))
+        if prior in ("l2", "l1", "laplace"):          # ... and with an array-valued epsg (one weight per pixel: lmc_problem.prox_scale)
+            eps = rng.uniform(0.3, 2.5, shape)
+            smp = la.MYULASampler(f, g, shape, n_chains=C_, tau=TAU, gamma=GAM, epsg=eps, noise="injected")
+            smp.set_state(x0)
+            smp.step(nit, noise=noise)
+            got = smp.get_state().cpu().numpy()
+            name = smp.kernel_name
+            smp.close()
+            ref = np.stack([O.myula(of, og, x0[c].ravel(), TAU, GAM, epsg=eps.ravel(), niter=nit, noise=[noise[i, c].ravel() for i in range(nit)])[-1].reshape(shape)
+                            for c in range(C_)])
+            e = rel(got, ref)
+            if not (e < 5e-5):
+                bad.append((data, prior + "+epsg[]", ncvx, name, e))
     assert not bad, "\n".join(f"{d} {p} {n} {k} {e:.2e}" for d, p, n, k, e in bad)
 
 
