@@ -192,3 +192,39 @@ def test_class_methods_value_grad_prox_over_the_same_matrix(la, shape):
             if not np.allclose(val, ref, rtol=5e-5):
                 bad.append(("-", prior, "value", float(np.max(np.abs(val / ref - 1)))))
     assert not bad, "\n".join(f"{a} {b} {c} {e:.2e}" for a, b, c, e in bad)
+
+
+@pytest.mark.parametrize("shape", [(24, 136), (16, 264), (16, 512)])
+def test_a_forced_kernel_variant_either_computes_the_update_or_refuses(la, shape):
+    """`MYULASampler(..., variant=...)` pins the step kernel: a variant that does not cover the configuration must say so (LMC_E_UNSUPPORTED), never run
+    something else or a different update -- every variant x data term x prior x non-convex term against the checker."""
+    rng = np.random.default_rng(shape[1] + 3)
+    C_, nit = 2, 2
+    bad, ran = [], 0
+    for variant in ("tile", "split", "point", "block", "rows", "pipe"):
+        for data, prior, ncvx in itertools.product(["blur5", "blur7", "mask"], PRIORS, ["none", "mc"]):
+            if prior == "haar" and (shape[0] % 8 or shape[1] % 8):
+                continue
+            img, f, of, g, og = build(la, shape, data, prior, ncvx, rng)
+            x0 = img[None] + rng.normal(0, [[[3.0]], [[15.0]]], (C_,) + shape)
+            noise = rng.standard_normal((nit, C_) + shape)
+            smp = la.MYULASampler(f, g, shape, n_chains=C_, tau=TAU, gamma=GAM, noise="injected", variant=variant)
+            smp.set_state(x0)
+            try:
+                smp.step(nit, noise=noise)
+            except la.LMCError as err:
+                assert err.code == -2, (variant, data, prior, ncvx, err)
+                smp.close()
+                continue
+            got = smp.get_state().cpu().numpy()
+            name = smp.kernel_name
+            smp.close()
+            ran += 1
+            # (the per-chain early exit is a path of its own -- the RT pipeline, or the pass-by-pass prox in front of the pinned kernel: `variant` pins the fixed-count kernels)
+            if prior != "tv_rtol" and variant not in name:
+                bad.append((variant, data, prior, ncvx, name, -1.0))
+            ref = np.stack([O.myula(of, og, x0[c].ravel(), TAU, GAM, niter=nit, noise=[noise[i, c].ravel() for i in range(nit)])[-1].reshape(shape) for c in range(C_)])
+            e = rel(got, ref)
+            if not (e < 5e-5):
+                bad.append((variant, data, prior, ncvx, name, e))
+    assert ran > 40 and not bad, "\n".join(f"{v} {d} {p} {n} {k} {e:.2e}" for v, d, p, n, k, e in bad)
