@@ -228,3 +228,40 @@ def test_a_forced_kernel_variant_either_computes_the_update_or_refuses(la, shape
             if not (e < 5e-5):
                 bad.append((variant, data, prior, ncvx, name, e))
     assert ran > 40 and not bad, "\n".join(f"{v} {d} {p} {n} {k} {e:.2e}" for v, d, p, n, k, e in bad)
+
+
+@pytest.mark.parametrize("shape,C_", [((24, 136), 3), ((16, 512), 5), ((64, 512), 40)])
+def test_posterior_moments_over_launch_groupings_and_kernels(la, shape, C_):
+    """lmc_sampler_moments after ONE call of n iterations (which the library may run as pair / four-iteration launches, with the reductions on a side stream)
+    against the sums formed from the states of n single-iteration calls with the same Philox seed: burn-in and thinning, every prior family (so every
+    kernel family), both overlap policies."""
+    rng = np.random.default_rng(shape[1] + 4 + C_)
+    nit, burn, thin = 7, 2, 2
+    bad = []
+    for data, prior, ncvx in [("blur5", "tv", "none"), ("blur5", "tv_rtol", "none"), ("blur5", "l2", "none"), ("blur7", "l1", "none"), ("mask", "haar", "none"),
+                              ("mask", "haar", "mc"), ("identity", "laplace", "none"), ("blur5", "tv", "mc")]:
+        img, f, of, g, og = build(la, shape, data, prior, ncvx, rng)
+        x0 = img[None] + rng.normal(0, 10.0, (C_,) + shape)
+        ref_s1, ref_s2, cnt = np.zeros(shape), np.zeros(shape), 0
+        one = la.MYULASampler(f, g, shape, n_chains=C_, tau=TAU, gamma=GAM, seed=11)
+        one.set_state(x0)
+        for it in range(nit):
+            one.step(1)
+            if it >= burn and (it - burn) % thin == 0:
+                x = one.get_state().cpu().numpy().astype(np.float64)
+                ref_s1 += x.sum(0); ref_s2 += (x * x).sum(0); cnt += C_
+        final = one.get_state().cpu().numpy()
+        one.close()
+        for overlap, ipl in ((1, 0), (-1, 0), (1, 2), (-1, 2), (1, 1)):      # iterations_per_launch 2: pair / four-iteration launches wherever a kernel covers them
+            smp = la.MYULASampler(f, g, shape, n_chains=C_, tau=TAU, gamma=GAM, seed=11, moments=True, burn_in=burn, thin=thin,
+                                  policy={"moments_overlap": overlap, "iterations_per_launch": ipl})
+            smp.set_state(x0)
+            smp.step(nit)
+            s1, s2, n = smp.moments()
+            e1, e2 = rel(s1.cpu().numpy(), ref_s1), rel(s2.cpu().numpy(), ref_s2)
+            ef = rel(smp.get_state().cpu().numpy(), final)
+            name = smp.kernel_name
+            smp.close()
+            if n != cnt or not (e1 < 2e-6 and e2 < 4e-6 and ef < 1e-5):
+                bad.append((data, prior, ncvx, overlap, ipl, name, n, cnt, e1, e2, ef))
+    assert not bad, "\n".join(str(b) for b in bad)
