@@ -20,6 +20,9 @@ namespace lmc {
 #ifndef LMC_RT_SPREAD
 #define LMC_RT_SPREAD 1
 #endif
+#ifndef LMC_RT_CHAIN_MAP
+#define LMC_RT_CHAIN_MAP 1
+#endif
 #ifndef LMC_RT_MAP_SPREAD
 #define LMC_RT_MAP_SPREAD 3
 #endif
@@ -314,6 +317,7 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
     const unsigned code = A.ncvx_kind == LMC_NCVX_MC_TV ? 0x76354210u : (KT == 7 ? 0x75264310u : 0x76325410u);
     wave = (code >> (4 * hw_wave)) & 15;
   }
+  if constexpr (K == 10 && !RT && CHAIN) wave = (0x67325410u >> (4 * hw_wave)) & 15;      // links of a fixed-count chain: L + T2 | T1 + T3 | T4 + N | T5 + C (ME-TV, 50 passes: 13.27 vs 13.95 ms)
   if constexpr (RT && K == 10) {
 #ifndef LMC_RT_MAP
 #define LMC_RT_MAP 0
@@ -330,10 +334,11 @@ __global__ __launch_bounds__(64 * ((K + 1) / 2 + 3), (PXL == 8 || CHAIN) ? (WARM
       else if (LMC_RT_MAP == 1) wave = hw_wave == 4 ? 6 : hw_wave == 6 ? 4 : hw_wave;                                              // L + C | T1 + T5 | T2 + T4 | T3 + N
       else wave = hw_wave == 3 ? 6 : hw_wave == 4 ? 5 : hw_wave == 5 ? 4 : hw_wave == 6 ? 3 : hw_wave;                              // L + T5 | T1 + T4 | T2 + T3 | C + N
     }
+    else if (CHAIN && LMC_RT_CHAIN_MAP) wave = ((LMC_RT_CHAIN_MAP == 2 ? 0x76345210u : 0x67254310u) >> (4 * hw_wave)) & 15;       // all stages live, a link of a chained prox: L + T5 | T1 + T2 | T3 + N | T4 + C (ME-TV as configured: 15.95 vs 16.73 ms)
     else wave = hw_wave == 4 ? 6 : hw_wave == 6 ? 4 : hw_wave;        // more live stages: L + C | T1 + T5 | T2 + T4 | T3 + N
   }
 #ifdef LMC_EXP_PERM   // timing experiment (scripts/round3/perm_search.py): role of hardware wave w = nibble w of A.PH (the tile kernel's field, unused here)
-  if (A.PH) wave = (A.PH >> (4 * hw_wave)) & 15;
+  if (A.PH && (LMC_EXP_PERM == 1 || CHAIN)) wave = (A.PH >> (4 * hw_wave)) & 15;      // LMC_EXP_PERM=2: the chained links only
 #endif
   // column strip of this workgroup (blockIdx.y; one strip = the whole row when W <= 64 PXL): c0 is a GLOBAL column, LDS rows are indexed by lane
   constexpr int HALO = pipe_halo(K, KT, PXL);

@@ -19,7 +19,7 @@ f = la.L2(Op=Hop, b=img.ravel(), sigma=1 / sigma ** 2)
 if args.mc:
     f = la.L2_ncvx_tv(dims=(H, W), Op=Hop, Op2=la.Gradient((H, W)), b=img.ravel(), sigma=1 / sigma ** 2, lamda=0.3, gamma=15.0)
 if args.me:
-    f = la.L2_ncvx_tv(dims=(H, W), Op=Hop, b=img.ravel(), sigma=1 / sigma ** 2, lamda=0.3, gamma=15.0, niter=50, rtol=1e-4)
+    f = la.L2_ncvx_tv(dims=(H, W), Op=Hop, b=img.ravel(), sigma=1 / sigma ** 2, lamda=0.3, gamma=15.0, isotropic=True, niter=50, rtol=args.rtol)
 g = la.TV((H, W), sigma=0.3, niter=10, rtol=args.rtol)
 smp = la.MYULASampler(f, g, (H, W), n_chains=C, tau=0.2 * sigma ** 2, gamma=sigma ** 2, seed=0)
 smp.set_state(np.zeros((H, W), dtype=np.float32))
