@@ -392,7 +392,7 @@ def main():
                 "perfectly_balanced": 1.16 * C / 1024.0, "whole_waves_on_simds": 1.29 * C / 1024.0,
                 "how": "SQ_ACTIVE_INST_VALU (4-cycle issue slots) of the shipped kernel and of free-running single-role builds (profiles/r03_pipe_role_counters.txt): "
                        "per tick L 165, T1 159, T2..T5 190.5 each, C 52, N 163 = 1281 slots per CU; 320 per SIMD (541 ns at 2.37 GHz) if it could be split evenly; with "
-                       "whole waves on SIMDs the busiest pair (L + T4) carries 355.5 (600 ns); x 536 ticks x 4 rounds of 256 workgroups"}
+                       "whole waves on SIMDs the busiest pair (L beside a two-stage TV wave, whatever the pairing) carries 355.5 (600 ns); x 536 ticks x 4 rounds of 256 workgroups"}
         if headline and not args.tv_rtol and world == 1 and os.environ.get("LMC_BENCH_AS_CONFIGURED", "1") != "0":
             # beside the headline (fixed K = 10 passes): the same chain AS THE REFERENCE IS CONFIGURED -- pyproximal.TV's default rtol = 1e-4, which
             # prox_lmc_deconv.py:122 leaves in force; the exit is decided on the device, chain by chain.  60 warm-up iterations: the pass counts
